@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY. Generates tests/golden/*.npz by running the reference's own kernel text
+(oracle/_ref, built by `make -C oracle ref` from /root/reference/src_kernels_cuda/*.cu, executed on the host).
+
+Run in the build container only (it needs /root/reference):   python oracle/make_golden.py
+The committed fixtures are DATA: seeded inputs + the outputs of the reference kernels. The k-distribution is
+regenerated from its seed by the tests (rte-rrtmgp-cpp_amd/synthetic.py) and verified against the stored digest.
+
+Cases: chained gas optics -> Planck -> LW solver -> sum, and
+gas optics + Rayleigh -> combine -> SW solver -> sum, both vertical orientations, fp64 and fp32; plus
+random-input solver cases in the style of tuning_kernels_cuda/{lw_solver_noscat,sw_source_adding_kernel}.py and the
+element-wise optical-props kernels.
+"""
+import hashlib
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_py as O                                            # noqa: E402
+from rte_rrtmgp_cpp_amd import synthetic, pipeline               # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+MINI = dict(ngpt=32, nbnd=2, npres=10, nflav=3, nminor_lower=5, nminor_upper=3)
+
+
+def kdist_digest(kd):
+    h = hashlib.sha256()
+    for k in sorted(kd.__dict__):
+        v = kd.__dict__[k]
+        if isinstance(v, np.ndarray):
+            h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def chained_case(dtype, top_at_1, ncol, nlay):
+    ref = O.CpuKernels("ref", dtype)
+    out = {}
+    atm = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=2, nbnd_sw=2, top_at_1=top_at_1, seed=7).astype(dtype)
+    # host-side arithmetic of the reference's classes, in numpy (inputs of the kernels, stored in the fixture)
+    plev = atm.p_lev.astype(np.float64)
+    h2o = atm.vmr["h2o"].astype(np.float64)
+    m_air = (0.028964 + 0.018016*h2o) / (1. + h2o)
+    col_dry = (10.*np.abs(plev[:-1] - plev[1:])*6.02214076e23 / (1000.*m_air*100.*9.80665) / (1. + h2o)).astype(dtype)
+    for kind in ("lw", "sw"):
+        kd = synthetic.make_kdist(kind, **MINI)
+        out[f"{kind}_kdist_digest"] = np.array(kdist_digest(kd))
+        kd = ref.upload_kdist(kd)
+        col_gas = ref.fill_gases(kd, atm.vmr, col_dry)
+        it = ref.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+        if kind == "lw":
+            out.update(p_lay=atm.p_lay, p_lev=atm.p_lev, t_lay=atm.t_lay, t_lev=atm.t_lev, t_sfc=atm.t_sfc,
+                       col_dry=col_dry, col_gas=col_gas, **{f"vmr_{n}": v for n, v in atm.vmr.items()})
+            out.update({f"lw_it_{k}": v for k, v in it.items()})
+            tau = ref.zeros((kd.ngpt, nlay, ncol))
+            ref.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
+            src = ref.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, nlay if top_at_1 else 1)
+            emis = np.ascontiguousarray(np.repeat(atm.emis_sfc.T, kd.ngpt // kd.nbnd, axis=0))
+            sec = ref.lw_secants_array(ncol, kd.ngpt, 1, 4, ref.asarray(pipeline.GAUSS_DS))
+            fl = ref.lw_solver_noscat(top_at_1, sec, ref.asarray(np.array([1.0])), tau, src["lay_src"], src["lev_src"],
+                                      emis, src["sfc_src"])
+            out.update(lw_tau=tau, lw_lay_src=src["lay_src"], lw_lev_src=src["lev_src"], lw_sfc_src=src["sfc_src"],
+                       lw_sfc_src_jac=src["sfc_src_jac"], lw_sfc_emis_gpt=emis, lw_secants=sec,
+                       lw_gpt_flux_up=fl["flux_up"], lw_gpt_flux_dn=fl["flux_dn"],
+                       lw_flux_up=ref.sum_broadband(fl["flux_up"]), lw_flux_dn=ref.sum_broadband(fl["flux_dn"]))
+            out["lw_flux_net"] = ref.net_broadband_precalc(out["lw_flux_dn"], out["lw_flux_up"])
+        else:
+            out.update({f"sw_it_{k}": v for k, v in it.items()})
+            tau_abs = ref.zeros((kd.ngpt, nlay, ncol))
+            ref.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau_abs)
+            tau_ray = ref.compute_tau_rayleigh(kd, it, col_dry, col_gas)
+            tau, ssa, g = ref.combine_abs_and_rayleigh(tau_abs, tau_ray)
+            toa = (kd.solar_source[:, None] * atm.tsi_scaling[None, :]).astype(dtype)
+            adir = np.ascontiguousarray(np.repeat(atm.sfc_alb_dir.T, kd.ngpt // kd.nbnd, axis=0))
+            adif = np.ascontiguousarray(np.repeat(atm.sfc_alb_dif.T, kd.ngpt // kd.nbnd, axis=0))
+            fl = ref.sw_solver_2stream(top_at_1, tau, ssa, g, atm.mu0, adir, adif, toa)
+            out.update(sw_tau_abs=tau_abs, sw_tau_ray=tau_ray, sw_tau=tau, sw_ssa=ssa, sw_g=g, sw_toa_src=toa,
+                       sw_alb_dir=adir, sw_alb_dif=adif, mu0=atm.mu0,
+                       sw_gpt_flux_up=fl["flux_up"], sw_gpt_flux_dn=fl["flux_dn"], sw_gpt_flux_dir=fl["flux_dir"],
+                       sw_flux_up=ref.sum_broadband(fl["flux_up"]), sw_flux_dn=ref.sum_broadband(fl["flux_dn"]),
+                       sw_flux_dir=ref.sum_broadband(fl["flux_dir"]))
+    out["meta"] = np.array([ncol, nlay, int(top_at_1), 7])
+    return out
+
+
+def random_solver_case(dtype, top_at_1, ncol, nlay, ngpt, seed):
+    """Random optical properties (tuning_kernels_cuda/lw_solver_noscat.py:161-192 style), incl. the
+    conservative-scattering and thick/thin limits that exercise the k_min / tmin / Ukkonen clamps."""
+    ref = O.CpuKernels("ref", dtype)
+    rng = np.random.default_rng(seed)
+    shp = (ngpt, nlay, ncol)
+    tau = (10.0**rng.uniform(-6, 2, shp)).astype(dtype)
+    tau[0, 0, :] = 0.0                                    # tau == 0 -> series branch of `fact`
+    lay = rng.uniform(5., 40., shp).astype(dtype)
+    lev = rng.uniform(5., 40., (ngpt, nlay+1, ncol)).astype(dtype)
+    emis = rng.uniform(0.8, 1.0, (ngpt, ncol)).astype(dtype)
+    ssrc = rng.uniform(5., 40., (ngpt, ncol)).astype(dtype)
+    sjac = rng.uniform(0.1, 1.0, (ngpt, ncol)).astype(dtype)
+    sec = ref.lw_secants_array(ncol, ngpt, 1, 4, ref.asarray(pipeline.GAUSS_DS))
+    fl = ref.lw_solver_noscat(top_at_1, sec, ref.asarray(np.array([1.0])), tau, lay, lev, emis, ssrc, sfc_src_jac=sjac)
+    out = dict(lw_tau=tau, lw_lay_src=lay, lw_lev_src=lev, lw_emis=emis, lw_sfc_src=ssrc, lw_sfc_src_jac=sjac,
+               lw_flux_up=fl["flux_up"], lw_flux_dn=fl["flux_dn"], lw_flux_up_jac=fl["flux_up_jac"])
+
+    ssa = rng.uniform(0., 1., shp).astype(dtype)
+    ssa[1, :, :] = 1.0                                    # conservative scattering -> k_min clamp
+    ssa[2, :, :] = 0.0
+    g = rng.uniform(-0.3, 0.9, shp).astype(dtype)
+    mu0 = rng.uniform(0.05, 1.0, ncol).astype(dtype)
+    adir_col = rng.uniform(0., 0.6, ncol).astype(dtype)   # band-uniform direct albedo
+    adir = np.ascontiguousarray(np.repeat(adir_col[None, :], ngpt, axis=0))
+    adif = rng.uniform(0., 0.6, (ngpt, ncol)).astype(dtype)
+    inc = rng.uniform(0., 5., (ngpt, ncol)).astype(dtype)
+    inc_dif = rng.uniform(0., 1., (ngpt, ncol)).astype(dtype)
+    fs = ref.sw_solver_2stream(top_at_1, tau, ssa, g, mu0, adir, adif, inc)
+    fd = ref.sw_solver_2stream(top_at_1, tau, ssa, g, mu0, adir, adif, inc, inc_dif)
+    out.update(sw_ssa=ssa, sw_g=g, mu0=mu0, sw_alb_dir=adir, sw_alb_dif=adif, sw_inc_dir=inc, sw_inc_dif=inc_dif,
+               sw_flux_up=fs["flux_up"], sw_flux_dn=fs["flux_dn"], sw_flux_dir=fs["flux_dir"],
+               sw_dif_flux_up=fd["flux_up"], sw_dif_flux_dn=fd["flux_dn"])
+
+    # element-wise optical-props kernels
+    t1, w1, g1 = tau.copy(), ssa.copy(), g.copy()
+    t2 = (10.0**rng.uniform(-4, 1, shp)).astype(dtype); w2 = rng.uniform(0., 1., shp).astype(dtype); g2 = rng.uniform(0., 0.9, shp).astype(dtype)
+    ref.increment_2stream_by_2stream(t1, w1, g1, t2, w2, g2)
+    out.update(op_t2=t2, op_w2=w2, op_g2=g2, op_inc2_tau=t1, op_inc2_ssa=w1, op_inc2_g=g1)
+    t1 = tau.copy(); ref.increment_1scalar_by_1scalar(t1, t2); out["op_inc1_tau"] = t1
+    nb = 2
+    lims = np.array([[1, ngpt//2], [ngpt//2+1, ngpt]], dtype=np.int32)
+    tb = (10.0**rng.uniform(-3, 1, (nb, nlay, ncol))).astype(dtype); wb = rng.uniform(0., 1., (nb, nlay, ncol)).astype(dtype); gb = rng.uniform(0., 0.9, (nb, nlay, ncol)).astype(dtype)
+    t1, w1, g1 = tau.copy(), ssa.copy(), g.copy()
+    ref.inc_2stream_by_2stream_bybnd(t1, w1, g1, tb, wb, gb, lims)
+    out.update(op_lims=lims, op_tb=tb, op_wb=wb, op_gb=gb, op_incb2_tau=t1, op_incb2_ssa=w1, op_incb2_g=g1)
+    t1 = tau.copy(); ref.inc_1scalar_by_1scalar_bybnd(t1, tb, lims); out["op_incb1_tau"] = t1
+    t1, w1, g1 = tau.copy(), ssa.copy(), g.copy()
+    ref.delta_scale_2str_k(t1, w1, g1)
+    out.update(op_ds_tau=t1, op_ds_ssa=w1, op_ds_g=g1)
+    out["meta"] = np.array([ncol, nlay, int(top_at_1), seed])
+    return out
+
+
+def main():
+    O.build(ref=True)
+    os.makedirs(GOLDEN, exist_ok=True)
+    total = 0
+    for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        for top in (False, True):
+            ncol, nlay = (3, 30) if dtype == np.float64 else (2, 12)
+            for name, case in (
+                    (f"chain_{tag}_top{int(top)}", chained_case(dtype, top, ncol, nlay)),
+                    (f"random_{tag}_top{int(top)}", random_solver_case(dtype, top, 5, 19, 8, 11 + int(top)))):
+                path = os.path.join(GOLDEN, name + ".npz")
+                np.savez_compressed(path, **case)
+                total += os.path.getsize(path)
+                print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+    # degenerate shape: 1 column x 4 layers
+    case = chained_case(np.float64, False, 1, 4)
+    path = os.path.join(GOLDEN, "chain_f64_top0_1x4.npz")
+    np.savez_compressed(path, **case)
+    total += os.path.getsize(path)
+    print(f"total {total/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

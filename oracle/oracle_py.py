@@ -1,0 +1,308 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy/ctypes bindings of the CPU checkers.
+
+  CpuKernels("oracle", dtype)  -> oracle/_build/liboracle_{dp,sp}.so : the CPU restatement (rrtmgp_oracle.cpp),
+                                  Fortran bind(C) names and calling convention of include/rrtmgp_kernels.h
+  CpuKernels("ref", dtype)     -> oracle/_ref/libref_{dp,sp}.so     : the reference's own kernel text executed
+                                  on the host (ref_runner.cpp); only exists where `make -C oracle ref` was run
+
+Both expose the launcher-level method names of rte-rrtmgp-cpp_amd/hip_kernels.py, so the package's pipeline.py can
+be driven by either. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import os
+import subprocess
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+import rte_rrtmgp_cpp_amd  # noqa: E402  (for the shared ctypes marshalling helper and KDist only)
+from rte_rrtmgp_cpp_amd._ffi import Lib, BoolArg  # noqa: E402
+
+
+def build(ref=True, quiet=True):
+    """Compile the oracle (and oracle/_ref when /root/reference is present). Building the checker is not using it."""
+    targets = ["all"]
+    if ref and os.path.isdir("/root/reference/src_kernels_cuda"):
+        targets.append("ref")
+    subprocess.run(["make", "-C", _HERE] + targets, check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib_path(kind, dtype):
+    sfx = "dp" if np.dtype(dtype) == np.float64 else "sp"
+    if kind == "oracle":
+        return os.path.join(_HERE, "_build", f"liboracle_{sfx}.so")
+    return os.path.join(_HERE, "_ref", f"libref_{sfx}.so")
+
+
+def have(kind, dtype=np.float64):
+    return os.path.exists(lib_path(kind, dtype))
+
+
+class CpuKernels:
+    def __init__(self, kind="oracle", dtype=np.float64):
+        assert kind in ("oracle", "ref")
+        self.kind = kind
+        self.name = kind
+        self.np_dtype = np.dtype(dtype)
+        path = lib_path(kind, dtype)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not built (run `make -C oracle`" + (" ref`)" if kind == "ref" else "`)"))
+        self.lib = Lib(path, self.np_dtype, by_ref=(kind == "oracle"))
+
+    # ---- array helpers (numpy) ----
+    def asarray(self, a):
+        a = np.ascontiguousarray(a)
+        return a.astype(self.np_dtype) if a.dtype.kind == "f" else a
+
+    def to_numpy(self, a):
+        return a
+
+    def empty(self, shape, dtype=None):
+        return np.zeros(shape, dtype=dtype or self.np_dtype)
+
+    zeros = empty
+
+    def int_empty(self, shape):
+        return np.zeros(shape, dtype=np.int32)
+
+    def bool_empty(self, shape):
+        return np.zeros(shape, dtype=np.int8)
+
+    def synchronize(self):
+        pass
+
+    def upload_kdist(self, kd):
+        return kd.astype(self.np_dtype)
+
+    def upload_lut(self, lut):
+        return {k: (self.asarray(v) if isinstance(v, np.ndarray) else v) for k, v in lut.items()}
+
+    @property
+    def is_oracle(self):
+        return self.kind == "oracle"
+
+    def _F(self, x):
+        return self.np_dtype.type(x)
+
+    # ---- solvers ----
+    def lw_secants_array(self, ncol, ngpt, n_quad, max_pts, gauss_Ds):
+        if self.is_oracle:      # CPU path: plain loop in src/Rte_lw.cpp:170-174
+            sec = np.empty((n_quad, ngpt, ncol), dtype=self.np_dtype)
+            for imu in range(n_quad):
+                sec[imu] = gauss_Ds.reshape(max_pts, max_pts)[n_quad-1, imu]
+            return sec
+        sec = self.empty((n_quad, ngpt, ncol))
+        self.lib.call("ref_lw_secants_array", ncol, ngpt, n_quad, max_pts, gauss_Ds, sec)
+        return sec
+
+    def lw_solver_noscat(self, top_at_1, secants, weights, tau, lay_source, lev_source, sfc_emis, sfc_src,
+                         inc_flux=None, do_broadband=False, do_jacobians=False, sfc_src_jac=None):
+        ngpt, nlay, ncol = tau.shape
+        nmus = weights.shape[0]
+        if self.is_oracle:
+            if do_broadband:
+                up = self.empty((nlay+1, ncol)); dn = self.empty((nlay+1, ncol))
+                gu = gd = self.empty((1,))
+            else:
+                gu = self.empty((ngpt, nlay+1, ncol)); gd = self.empty((ngpt, nlay+1, ncol))
+                up, dn = gu, gd
+            jac = self.empty((ngpt, nlay+1, ncol)) if do_jacobians else self.empty((1,))
+            sj = sfc_src_jac if sfc_src_jac is not None else self.empty((ngpt, ncol))
+            self.lib.call("rte_lw_solver_noscat", ncol, nlay, ngpt, BoolArg(top_at_1), nmus, secants, weights,
+                          tau, lay_source, lev_source, sfc_emis, sfc_src, inc_flux, gu, gd,
+                          BoolArg(do_broadband), up, dn, BoolArg(do_jacobians), sj, jac,
+                          BoolArg(False), tau, tau)
+            out = dict(flux_up=up, flux_dn=dn)
+            if do_jacobians:
+                out["flux_up_jac"] = jac
+            return out
+        assert not do_broadband, "the reference GPU kernels have no broadband mode (SURVEY Q5)"
+        gu = self.empty((ngpt, nlay+1, ncol)); gd = self.empty((ngpt, nlay+1, ncol)); jac = self.empty((ngpt, nlay+1, ncol))
+        sj = sfc_src_jac if sfc_src_jac is not None else self.empty((ngpt, ncol))
+        self.lib.call("ref_lw_solver_noscat", ncol, nlay, ngpt, BoolArg(top_at_1), nmus, secants, weights,
+                      tau, lay_source, lev_source, sfc_emis, sfc_src, inc_flux, gu, gd, sj, jac)
+        return dict(flux_up=gu, flux_dn=gd, flux_up_jac=jac)
+
+    def sw_solver_2stream(self, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir,
+                          inc_flux_dif=None, do_broadband=False):
+        ngpt, nlay, ncol = tau.shape
+        if self.is_oracle:
+            mu2 = mu0 if mu0.ndim == 2 else np.ascontiguousarray(np.repeat(mu0[None, :], nlay, axis=0))
+            if do_broadband:
+                up = self.empty((nlay+1, ncol)); dn = self.empty((nlay+1, ncol)); dr = self.empty((nlay+1, ncol))
+                gu = gd = gr = self.empty((1,))
+            else:
+                gu = self.empty((ngpt, nlay+1, ncol)); gd = self.empty((ngpt, nlay+1, ncol)); gr = self.empty((ngpt, nlay+1, ncol))
+                up, dn, dr = gu, gd, gr
+            self.lib.call("rte_sw_solver_2stream", ncol, nlay, ngpt, BoolArg(top_at_1), tau, ssa, g, mu2,
+                          sfc_alb_dir, sfc_alb_dif, inc_flux_dir, gu, gd, gr,
+                          BoolArg(inc_flux_dif is not None), inc_flux_dif, BoolArg(do_broadband), up, dn, dr)
+            return dict(flux_up=up, flux_dn=dn, flux_dir=dr)
+        assert not do_broadband
+        mu1 = mu0 if mu0.ndim == 1 else np.ascontiguousarray(mu0[0])
+        gu = self.empty((ngpt, nlay+1, ncol)); gd = self.empty((ngpt, nlay+1, ncol)); gr = self.empty((ngpt, nlay+1, ncol))
+        self.lib.call("ref_sw_solver_2stream", ncol, nlay, ngpt, BoolArg(top_at_1), tau, ssa, g, mu1,
+                      sfc_alb_dir, sfc_alb_dif, inc_flux_dir, gu, gd, gr, inc_flux_dif)
+        return dict(flux_up=gu, flux_dn=gd, flux_dir=gr)
+
+    # ---- gas optics ----
+    def interpolation(self, kd, play, tlay, col_gas):
+        nlay, ncol = play.shape
+        r = dict(
+            jtemp=self.int_empty((nlay, ncol)), jpress=self.int_empty((nlay, ncol)), tropo=self.bool_empty((nlay, ncol)),
+            jeta=self.int_empty((kd.nflav, nlay, ncol, 2)), col_mix=self.empty((kd.nflav, nlay, ncol, 2)),
+            fminor=self.empty((kd.nflav, nlay, ncol, 2, 2)), fmajor=self.empty((kd.nflav, nlay, ncol, 2, 2, 2)))
+        name = "rrtmgp_interpolation" if self.is_oracle else "ref_interpolation"
+        self.lib.call(name, ncol, nlay, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp,
+                      kd.flavor, kd.press_ref_log, kd.temp_ref,
+                      self._F(kd.press_ref_log_delta), self._F(kd.temp_ref_min), self._F(kd.temp_ref_delta),
+                      self._F(kd.press_ref_trop_log),
+                      kd.vmr_ref, play, tlay, col_gas,
+                      r["jtemp"], r["fmajor"], r["fminor"], r["col_mix"], r["tropo"], r["jeta"], r["jpress"])
+        return r
+
+    def compute_tau_absorption(self, kd, it, play, tlay, col_gas, tau):
+        nlay, ncol = play.shape
+        name = "rrtmgp_compute_tau_absorption" if self.is_oracle else "ref_compute_tau_absorption"
+        self.lib.call(name, ncol, nlay, kd.nbnd, kd.ngpt, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp,
+                      kd.minor_limits_gpt_lower.shape[0], kd.kminor_lower.shape[0],
+                      kd.minor_limits_gpt_upper.shape[0], kd.kminor_upper.shape[0], kd.idx_h2o,
+                      kd.gpoint_flavor, kd.band_lims_gpt, kd.kmajor, kd.kminor_lower, kd.kminor_upper,
+                      kd.minor_limits_gpt_lower, kd.minor_limits_gpt_upper,
+                      kd.minor_scales_with_density_lower, kd.minor_scales_with_density_upper,
+                      kd.scale_by_complement_lower, kd.scale_by_complement_upper,
+                      kd.idx_minor_lower, kd.idx_minor_upper, kd.idx_minor_scaling_lower, kd.idx_minor_scaling_upper,
+                      kd.kminor_start_lower, kd.kminor_start_upper,
+                      it["tropo"], it["col_mix"], it["fmajor"], it["fminor"], play, tlay, col_gas,
+                      it["jeta"], it["jtemp"], it["jpress"], tau)
+        return tau
+
+    def compute_tau_rayleigh(self, kd, it, col_dry, col_gas):
+        nlay, ncol = col_dry.shape
+        tr = self.empty((kd.ngpt, nlay, ncol))
+        name = "rrtmgp_compute_tau_rayleigh" if self.is_oracle else "ref_compute_tau_rayleigh"
+        self.lib.call(name, ncol, nlay, kd.nbnd, kd.ngpt, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp,
+                      kd.gpoint_flavor, kd.band_lims_gpt, kd.krayl, kd.idx_h2o, col_dry, col_gas,
+                      it["fminor"], it["jeta"], it["tropo"], it["jtemp"], tr)
+        return tr
+
+    def combine_abs_and_rayleigh(self, tau_abs, tau_ray):
+        ngpt, nlay, ncol = tau_abs.shape
+        tau = self.empty(tau_abs.shape); ssa = self.empty(tau_abs.shape); g = self.empty(tau_abs.shape)
+        name = "oracle_combine_abs_and_rayleigh" if self.is_oracle else "ref_combine_abs_and_rayleigh"
+        self.lib.call(name, ncol, nlay, ngpt, tau_abs, tau_ray, tau, ssa, g)
+        return tau, ssa, g
+
+    def compute_planck_source(self, kd, it, tlay, tlev, tsfc, sfc_lay, out=None):
+        nlay, ncol = tlay.shape
+        out = dict(sfc_src=self.empty((kd.ngpt, ncol)), lay_src=self.empty((kd.ngpt, nlay, ncol)),
+                   lev_src=self.empty((kd.ngpt, nlay+1, ncol)), sfc_src_jac=self.empty((kd.ngpt, ncol)))
+        name = "rrtmgp_compute_Planck_source" if self.is_oracle else "ref_compute_planck_source"
+        self.lib.call(name, ncol, nlay, kd.nbnd, kd.ngpt, kd.nflav, kd.neta, kd.npres, kd.ntemp, kd.nPlanckTemp,
+                      tlay, tlev, tsfc, sfc_lay, it["fmajor"], it["jeta"], it["tropo"], it["jtemp"], it["jpress"],
+                      kd.gpoint_bands, kd.band_lims_gpt, kd.planck_frac, self._F(kd.temp_ref_min), self._F(kd.totplnk_delta),
+                      kd.totplnk, kd.gpoint_flavor, out["sfc_src"], out["lay_src"], out["lev_src"], out["sfc_src_jac"])
+        return out
+
+    # ---- optical props / fluxes ----
+    def _nm(self, oracle_name, ref_name):
+        return oracle_name if self.is_oracle else ref_name
+
+    def increment_1scalar_by_1scalar(self, tau_inout, tau_in):
+        ngpt, nlay, ncol = tau_inout.shape
+        self.lib.call(self._nm("rte_increment_1scalar_by_1scalar", "ref_increment_1scalar_by_1scalar"), ncol, nlay, ngpt, tau_inout, tau_in)
+
+    def increment_2stream_by_2stream(self, t1, w1, g1, t2, w2, g2):
+        ngpt, nlay, ncol = t1.shape
+        self.lib.call(self._nm("rte_increment_2stream_by_2stream", "ref_increment_2stream_by_2stream"), ncol, nlay, ngpt, t1, w1, g1, t2, w2, g2)
+
+    def inc_1scalar_by_1scalar_bybnd(self, tau_inout, tau_in, band_lims):
+        ngpt, nlay, ncol = tau_inout.shape
+        self.lib.call(self._nm("rte_inc_1scalar_by_1scalar_bybnd", "ref_inc_1scalar_by_1scalar_bybnd"), ncol, nlay, ngpt, tau_inout, tau_in, band_lims.shape[0], band_lims)
+
+    def inc_2stream_by_2stream_bybnd(self, t1, w1, g1, t2, w2, g2, band_lims):
+        ngpt, nlay, ncol = t1.shape
+        self.lib.call(self._nm("rte_inc_2stream_by_2stream_bybnd", "ref_inc_2stream_by_2stream_bybnd"), ncol, nlay, ngpt, t1, w1, g1, t2, w2, g2, band_lims.shape[0], band_lims)
+
+    def delta_scale_2str_k(self, tau, ssa, g):
+        ngpt, nlay, ncol = tau.shape
+        self.lib.call(self._nm("rte_delta_scale_2str_k", "ref_delta_scale_2str_k"), ncol, nlay, ngpt, tau, ssa, g)
+
+    def sum_broadband(self, gpt_flux, out=None):
+        ngpt, nlev, ncol = gpt_flux.shape
+        out = self.empty((nlev, ncol))
+        self.lib.call(self._nm("rte_sum_broadband", "ref_sum_broadband"), ncol, nlev, ngpt, gpt_flux, out)
+        return out
+
+    def net_broadband_precalc(self, flux_dn, flux_up, out=None):
+        nlev, ncol = flux_dn.shape
+        out = self.empty((nlev, ncol))
+        self.lib.call(self._nm("rte_net_broadband_precalc", "ref_net_broadband_precalc"), ncol, nlev, flux_dn, flux_up, out)
+        return out
+
+    def sum_byband(self, gpt_flux, band_lims):
+        assert self.is_oracle, "the reference CUDA by-band kernels are buggy (SURVEY Q6); F90 semantics live in the oracle"
+        ngpt, nlev, ncol = gpt_flux.shape
+        out = self.empty((band_lims.shape[0], nlev, ncol))
+        self.lib.call("sum_byband", ncol, nlev, ngpt, band_lims.shape[0], band_lims, gpt_flux, out)
+        return out
+
+    def net_byband_full(self, gpt_dn, gpt_up, band_lims):
+        assert self.is_oracle
+        ngpt, nlev, ncol = gpt_dn.shape
+        out = self.empty((band_lims.shape[0], nlev, ncol))
+        self.lib.call("net_byband_full", ncol, nlev, ngpt, band_lims.shape[0], band_lims, gpt_dn, gpt_up, out)
+        return out
+
+    # ---- host-class helpers (oracle only; plain numpy where the reference has plain loops) ----
+    def get_col_dry(self, vmr_h2o, plev):
+        assert self.is_oracle
+        nlay, ncol = vmr_h2o.shape
+        out = self.empty((nlay, ncol))
+        self.lib.call("oracle_get_col_dry", ncol, nlay, vmr_h2o, plev, out)
+        return out
+
+    def fill_gases(self, kd, vmr_by_name, col_dry):
+        # /root/reference/src/Gas_optics_rrtmgp.cpp:1121-1160
+        nlay, ncol = col_dry.shape
+        col_gas = self.empty((kd.ngas+1, nlay, ncol))
+        col_gas[0] = col_dry
+        for i, name in enumerate(kd.gas_names, start=1):
+            col_gas[i] = np.broadcast_to(vmr_by_name[name], (nlay, ncol)) * col_dry
+        return col_gas
+
+    def expand_and_transpose(self, band_lims, arr_in, ngpt):
+        assert self.is_oracle
+        ncol, nbnd = arr_in.shape
+        out = self.empty((ngpt, ncol))
+        self.lib.call("oracle_expand_and_transpose", ncol, nbnd, ngpt, band_lims, arr_in, out)
+        return out
+
+    def spread_col(self, ncol, solar_source):
+        return np.ascontiguousarray(np.repeat(solar_source[:, None], ncol, axis=1))
+
+    def scaling_to_subset(self, toa_src, tsi_scaling):
+        toa_src *= tsi_scaling[None, :]
+
+    def _cloud_args(self, lut, clwp, ciwp, reliq, deice):
+        nlay, ncol = clwp.shape
+        nbnd = lut["lut_extliq"].shape[0]
+        return (ncol, nlay, nbnd, lut["nsize_liq"], lut["nsize_ice"],
+                self._F(lut["radliq_lwr"]), self._F(lut["radliq_upr"]), self._F(lut["diamice_lwr"]), self._F(lut["diamice_upr"]),
+                lut["lut_extliq"], lut["lut_ssaliq"], lut["lut_asyliq"], lut["lut_extice"], lut["lut_ssaice"], lut["lut_asyice"],
+                clwp, ciwp, reliq, deice), (nbnd, nlay, ncol)
+
+    def cloud_optics_2str(self, lut, clwp, ciwp, reliq, deice):
+        assert self.is_oracle
+        args, shp = self._cloud_args(lut, clwp, ciwp, reliq, deice)
+        tau = self.empty(shp); ssa = self.empty(shp); g = self.empty(shp)
+        self.lib.call("oracle_cloud_optics_2str", *args, tau, ssa, g)
+        return tau, ssa, g
+
+    def cloud_optics_1scl(self, lut, clwp, ciwp, reliq, deice):
+        assert self.is_oracle
+        args, shp = self._cloud_args(lut, clwp, ciwp, reliq, deice)
+        tau = self.empty(shp)
+        self.lib.call("oracle_cloud_optics_1scl", *args, tau)
+        return tau

@@ -1,0 +1,101 @@
+// Shared device/host helpers for the rrx HIP kernels (gfx950 / CDNA4 only).
+#ifndef RRX_COMMON_H
+#define RRX_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+#include <string>
+
+typedef signed char Bool;   // RTE_USE_CBOOL in every shipped reference config (config/ubuntu_22lts.cmake:35)
+
+namespace rrx
+{
+    // ---- error plumbing: C-ABI functions return int, message retrievable with rrx_last_error() ----
+    void set_error(const std::string& msg);
+    int check_launch(const char* what);
+
+    constexpr int WAVE = 64;
+
+    template<typename F> struct Lim;
+    template<> struct Lim<double>
+    {
+        __host__ __device__ static constexpr double eps() { return DBL_EPSILON; }
+        __host__ __device__ static constexpr double tiny() { return DBL_MIN; }
+        __host__ __device__ static constexpr double k_min() { return 1.e-12; }
+    };
+    template<> struct Lim<float>
+    {
+        __host__ __device__ static constexpr float eps() { return FLT_EPSILON; }
+        __host__ __device__ static constexpr float tiny() { return FLT_MIN; }
+        __host__ __device__ static constexpr float k_min() { return 1.e-4f; }
+    };
+
+    // ---- cross-lane moves (wave64). ds_bpermute-based shuffles of 32/64-bit values ----
+    __device__ __forceinline__ float shfl(const float v, const int src_lane) { return __shfl(v, src_lane, WAVE); }
+    __device__ __forceinline__ double shfl(const double v, const int src_lane) { return __shfl(v, src_lane, WAVE); }
+
+    // ---- vector-of-columns helpers: V consecutive columns handled by one lane ----
+    template<typename F, int V> struct Vec { F v[V]; };
+
+    template<typename F, int V>
+    __device__ __forceinline__ Vec<F,V> load_cols(const F* __restrict__ p, const int nvalid)
+    {
+        // p points at the first of V consecutive columns; nvalid (1..V) of them exist.
+        Vec<F,V> r;
+        if constexpr (V == 1)
+        {
+            r.v[0] = p[0];
+        }
+        else
+        {
+            if (nvalid == V)
+            {
+                typedef F vecT __attribute__((ext_vector_type(V)));
+                // rows are only guaranteed sizeof(F)-aligned when ncol % V != 0; the launcher picks V accordingly.
+                const vecT t = *reinterpret_cast<const vecT*>(p);
+                #pragma unroll
+                for (int i=0; i<V; ++i) r.v[i] = t[i];
+            }
+            else
+            {
+                #pragma unroll
+                for (int i=0; i<V; ++i) r.v[i] = p[i < nvalid ? i : 0];
+            }
+        }
+        return r;
+    }
+
+    template<typename F, int V>
+    __device__ __forceinline__ void store_cols(F* __restrict__ p, const Vec<F,V>& r, const int nvalid)
+    {
+        if constexpr (V == 1)
+        {
+            p[0] = r.v[0];
+        }
+        else
+        {
+            if (nvalid == V)
+            {
+                typedef F vecT __attribute__((ext_vector_type(V)));
+                vecT t;
+                #pragma unroll
+                for (int i=0; i<V; ++i) t[i] = r.v[i];
+                *reinterpret_cast<vecT*>(p) = t;
+            }
+            else
+            {
+                #pragma unroll
+                for (int i=0; i<V; ++i) if (i < nvalid) p[i] = r.v[i];
+            }
+        }
+    }
+
+    inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
+}
+
+#define RRX_TRY try {
+#define RRX_CATCH(name) } catch (const std::exception& e) { rrx::set_error(std::string(name) + ": " + e.what()); return 1; } \
+    return rrx::check_launch(name);
+
+#endif

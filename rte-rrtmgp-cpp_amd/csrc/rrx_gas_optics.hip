@@ -1,0 +1,666 @@
+// Gas optics: interpolation, major+minor absorption, Rayleigh, combine, Planck source.
+// Replaces Gas_optics_rrtmgp_kernels_cuda::* (/root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels_launchers.cu)
+// and the kernels of /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu.
+//
+// MI355X design (DESIGN.md section "gas optics"): one thread per (column, layer) cell, lanes = 64 consecutive
+// columns of one layer, each thread loops over the g-points. The per-cell interpolation state (jtemp, jpress,
+// jeta, col_mix, fmajor, fminor of the current flavor) stays in registers, so it is read once per flavor change
+// instead of once per g-point, and every (col,lay,gpt) output is written exactly once, coalesced over columns
+// (512 B per wave-store). The reference instead launches gpt-fastest threads that write uncoalesced and adds
+// major / minor-lower / minor-upper in three read-modify-write passes over tau.
+// The k-distribution tables are gathered through L1/L2 (neighbouring columns hit the same lines); the per-chunk
+// lists of minor contributors are built once per workgroup in LDS.
+#include "rrx_common.h"
+#include "rrx_hip.h"
+
+namespace
+{
+using namespace rrx;
+
+constexpr int GCH = 16;          // g-points per register chunk
+
+
+// /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:317-395
+template<typename F>
+__global__ void __launch_bounds__(256)
+interpolation_kernel(
+        const int ncol, const int nlay, const int ngas, const int nflav, const int neta, const int npres, const int ntemp,
+        const int* __restrict__ flavor, const F* __restrict__ press_ref_log, const F* __restrict__ temp_ref,
+        const F press_ref_log_delta, const F temp_ref_min, const F temp_ref_delta, const F press_ref_trop_log,
+        const F* __restrict__ vmr_ref, const F* __restrict__ play, const F* __restrict__ tlay,
+        const F* __restrict__ col_gas,
+        int* __restrict__ jtemp, F* __restrict__ fmajor, F* __restrict__ fminor, F* __restrict__ col_mix,
+        Bool* __restrict__ tropo, int* __restrict__ jeta, int* __restrict__ jpress)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    if (icol >= ncol || ilay >= nlay) return;
+
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const F tiny = Lim<F>::tiny();
+
+    const F t = tlay[idx];
+    int jt = int((t - (temp_ref_min - temp_ref_delta)) / temp_ref_delta);
+    jt = min(ntemp-1, max(1, jt));
+    jtemp[idx] = jt;
+    const F ftemp = (t - temp_ref[jt-1]) / temp_ref_delta;
+
+    const F lp = log(play[idx]);
+    const F locpress = F(1.) + (lp - press_ref_log[0]) / press_ref_log_delta;
+    const int jp = min(npres-1, max(1, int(locpress)));
+    jpress[idx] = jp;
+    const F fpress = locpress - F(jp);
+
+    const bool in_tropo = lp > press_ref_trop_log;
+    tropo[idx] = in_tropo;
+    const int itropo = in_tropo ? 0 : 1;
+
+    for (int iflav=0; iflav<nflav; ++iflav)
+    {
+        const int gas1 = flavor[2*iflav];
+        const int gas2 = flavor[2*iflav+1];
+        const size_t cell = idx + iflav*ncl;
+        const F cg1 = col_gas[idx + gas1*ncl];
+        const F cg2 = col_gas[idx + gas2*ncl];
+
+        #pragma unroll
+        for (int itemp=0; itemp<2; ++itemp)
+        {
+            const size_t vbase = itropo + size_t(jt+itemp-1) * (ngas+1) * 2;
+            const F ratio_eta_half = vmr_ref[vbase + 2*gas1] / vmr_ref[vbase + 2*gas2];
+            const F cmix = cg1 + ratio_eta_half * cg2;
+            col_mix[itemp + 2*cell] = cmix;
+
+            const F eta = (cmix > F(2.)*tiny) ? cg1 / cmix : F(0.5);
+            const F loceta = eta * F(neta-1);
+            jeta[itemp + 2*cell] = min(int(loceta)+1, neta-1);
+            const F feta = fmod(loceta, F(1.));
+            const F ftemp_term = F(1-itemp) + F(2*itemp-1)*ftemp;
+
+            const F f0 = (F(1.)-feta) * ftemp_term;
+            const F f1 = feta * ftemp_term;
+            F* fmi = &fminor[2*(itemp + 2*cell)];
+            fmi[0] = f0; fmi[1] = f1;
+            F* fma = &fmajor[4*(itemp + 2*cell)];
+            fma[0] = (F(1.)-fpress) * f0;
+            fma[1] = (F(1.)-fpress) * f1;
+            fma[2] = fpress * f0;
+            fma[3] = fpress * f1;
+        }
+    }
+}
+
+
+// Per-workgroup index of the minor contributors overlapping each 16-g-point chunk, built in LDS.
+// lists[r][c][0] = count, lists[r][c][1..] = interval ids in ascending order (deterministic summation order,
+// identical to the reference's sequential loop over imnr).
+struct MinorIndex
+{
+    int* base; int stride_c; int stride_r;
+    __device__ int count(int r, int c) const { return base[r*stride_r + c*stride_c]; }
+    __device__ int item(int r, int c, int i) const { return base[r*stride_r + c*stride_c + 1 + i]; }
+};
+
+__device__ inline MinorIndex build_minor_index(
+        int* lds, const int nchunk, const int nmax,
+        const int nminorlower, const int* __restrict__ lim_lower,
+        const int nminorupper, const int* __restrict__ lim_upper)
+{
+    MinorIndex mi{lds, 1 + nmax, nchunk*(1 + nmax)};
+    const int tid = threadIdx.y*blockDim.x + threadIdx.x;
+    const int nthr = blockDim.x*blockDim.y;
+    for (int w = tid; w < 2*nchunk; w += nthr)
+    {
+        const int r = w / nchunk, c = w % nchunk;
+        const int n = r == 0 ? nminorlower : nminorupper;
+        const int* lim = r == 0 ? lim_lower : lim_upper;
+        int cnt = 0;
+        for (int i=0; i<n; ++i)
+        {
+            const int lo = lim[2*i]-1, hi = lim[2*i+1];          // [lo, hi) zero-based
+            if (lo < (c+1)*GCH && hi > c*GCH)
+                lds[r*mi.stride_r + c*mi.stride_c + 1 + cnt++] = i;
+        }
+        lds[r*mi.stride_r + c*mi.stride_c] = cnt;
+    }
+    __syncthreads();
+    return mi;
+}
+
+
+// MODE 0: tau += major + minor            (compute_tau_absorption, reference semantics: caller zeroes tau)
+// MODE 1: tau/ssa/g = fused absorption + Rayleigh + combine   (SW gas optics in one pass)
+// major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
+// minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
+template<typename F, int MODE>
+__global__ void __launch_bounds__(256)
+tau_absorption_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
+        const int nminorlower, const int nminorupper, const int idx_h2o,
+        const int* __restrict__ gpoint_flavor,
+        const F* __restrict__ kmajor, const F* __restrict__ kminor_lower, const F* __restrict__ kminor_upper,
+        const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
+        const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
+        const Bool* __restrict__ scale_by_complement_lower, const Bool* __restrict__ scale_by_complement_upper,
+        const int* __restrict__ idx_minor_lower, const int* __restrict__ idx_minor_upper,
+        const int* __restrict__ idx_minor_scaling_lower, const int* __restrict__ idx_minor_scaling_upper,
+        const int* __restrict__ kminor_start_lower, const int* __restrict__ kminor_start_upper,
+        const Bool* __restrict__ tropo, const F* __restrict__ col_mix, const F* __restrict__ fmajor, const F* __restrict__ fminor,
+        const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
+        const int* __restrict__ jeta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
+        const F* __restrict__ krayl,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+{
+    extern __shared__ int lds[];
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const int nmax = max(nminorlower, nminorupper);
+    const MinorIndex mi = build_minor_index(lds, nchunk, nmax, nminorlower, minor_limits_gpt_lower,
+                                            nminorupper, minor_limits_gpt_upper);
+
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    if (icol >= ncol || ilay >= nlay) return;
+
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const int itropo = tropo[idx] ? 0 : 1;
+    const int jt = jtemp[idx];
+    const int jp = jpress[idx] + itropo;
+    const size_t s_eta = ntemp, s_prs = size_t(ntemp)*neta, s_gpt = size_t(ntemp)*neta*(npres+1);
+
+    const F pl = play[idx], tl = tlay[idx];
+    const F cdry0 = col_gas[idx];                         // col_gas(:,:,0) = col_dry
+    const F ch2o = col_gas[idx + size_t(idx_h2o)*ncl];
+    F ray_fac = F(0.);
+    if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
+
+    int cur_flav = -1;
+    F fm[8], cm[2], fmn[4];
+    int je[2];
+
+    for (int c=0; c<nchunk; ++c)
+    {
+        const int c0 = c*GCH;
+        F acc[GCH], ray[GCH];
+
+        // ---- major species
+        #pragma unroll
+        for (int u=0; u<GCH; ++u)
+        {
+            const int ig = min(c0 + u, ngpt-1);
+            const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
+            if (iflav != cur_flav)
+            {
+                cur_flav = iflav;
+                const size_t cell = idx + iflav*ncl;
+                #pragma unroll
+                for (int i=0; i<8; ++i) fm[i] = fmajor[8*cell + i];
+                cm[0] = col_mix[2*cell]; cm[1] = col_mix[2*cell+1];
+                je[0] = jeta[2*cell]; je[1] = jeta[2*cell+1];
+                if constexpr (MODE == 1)
+                {
+                    #pragma unroll
+                    for (int i=0; i<4; ++i) fmn[i] = fminor[4*cell + i];
+                }
+            }
+            F t = F(0.);
+            #pragma unroll
+            for (int i=0; i<2; ++i)
+            {
+                const size_t b = (jt-1+i) + size_t(ig)*s_gpt;
+                t += cm[i] *
+                    (fm[i*4+0] * kmajor[b + (je[i]-1)*s_eta + (jp-1)*s_prs] +
+                     fm[i*4+1] * kmajor[b +  je[i]   *s_eta + (jp-1)*s_prs] +
+                     fm[i*4+2] * kmajor[b + (je[i]-1)*s_eta +  jp   *s_prs] +
+                     fm[i*4+3] * kmajor[b +  je[i]   *s_eta +  jp   *s_prs]);
+            }
+            acc[u] = t;
+            if constexpr (MODE == 1)
+            {
+                const F* k = krayl + size_t(itropo)*ntemp*neta*ngpt + size_t(ig)*ntemp*neta;
+                ray[u] = ray_fac *
+                    (fmn[0] * k[(jt-1) + (je[0]-1)*ntemp] +
+                     fmn[1] * k[(jt-1) +  je[0]   *ntemp] +
+                     fmn[2] * k[ jt    + (je[1]-1)*ntemp] +
+                     fmn[3] * k[ jt    +  je[1]   *ntemp]);
+            }
+        }
+
+        // ---- minor species of this cell's regime (lower: r=0, upper: r=1)
+        for (int r=0; r<2; ++r)
+        {
+            const int n = mi.count(r, c);
+            const F* kminor = r == 0 ? kminor_lower : kminor_upper;
+            const int* lim = r == 0 ? minor_limits_gpt_lower : minor_limits_gpt_upper;
+            const Bool* swd = r == 0 ? minor_scales_with_density_lower : minor_scales_with_density_upper;
+            const Bool* sbc = r == 0 ? scale_by_complement_lower : scale_by_complement_upper;
+            const int* imn = r == 0 ? idx_minor_lower : idx_minor_upper;
+            const int* ims = r == 0 ? idx_minor_scaling_lower : idx_minor_scaling_upper;
+            const int* kst = r == 0 ? kminor_start_lower : kminor_start_upper;
+            for (int q=0; q<n; ++q)
+            {
+                const int imnr = mi.item(r, c, q);
+                if (itropo != r) continue;
+
+                F scaling = col_gas[idx + size_t(imn[imnr])*ncl];
+                if (swd[imnr])
+                {
+                    scaling *= F(0.01) * pl / tl;
+                    if (ims[imnr] > 0)
+                    {
+                        const F vmr_fact = F(1.) / cdry0;
+                        const F dry_fact = F(1.) / (F(1.) + ch2o * vmr_fact);
+                        const F x = col_gas[idx + size_t(ims[imnr])*ncl] * vmr_fact * dry_fact;
+                        scaling *= sbc[imnr] ? (F(1.) - x) : x;
+                    }
+                }
+                const int gpt_start = lim[2*imnr]-1;
+                const int gpt_end = lim[2*imnr+1];
+                const int iflav = gpoint_flavor[2*gpt_start + r] - 1;
+                const size_t cell = idx + iflav*ncl;
+                const F f0 = fminor[4*cell], f1 = fminor[4*cell+1], f2 = fminor[4*cell+2], f3 = fminor[4*cell+3];
+                const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
+                const int koff = kst[imnr]-1 - gpt_start;
+
+                #pragma unroll
+                for (int u=0; u<GCH; ++u)
+                {
+                    const int ig = c0 + u;
+                    if (ig >= gpt_start && ig < gpt_end)
+                    {
+                        const size_t kb = size_t(ig + koff)*ntemp*neta;
+                        const F k =
+                            f0 * kminor[(jt-1) + (j0-1)*ntemp + kb] +
+                            f1 * kminor[(jt-1) +  j0   *ntemp + kb] +
+                            f2 * kminor[ jt    + (j1-1)*ntemp + kb] +
+                            f3 * kminor[ jt    +  j1   *ntemp + kb];
+                        acc[u] += k * scaling;
+                    }
+                }
+            }
+        }
+
+        // ---- write out
+        #pragma unroll
+        for (int u=0; u<GCH; ++u)
+        {
+            const int ig = c0 + u;
+            if (ig < ngpt)
+            {
+                const size_t o = idx + size_t(ig)*ncl;
+                if constexpr (MODE == 0)
+                {
+                    tau[o] += acc[u];
+                }
+                else
+                {
+                    const F tt = acc[u] + ray[u];
+                    tau[o] = tt;
+                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
+                    g[o] = F(0.);
+                }
+            }
+        }
+    }
+}
+
+
+// /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:674-718 (standalone launcher parity)
+template<typename F>
+__global__ void __launch_bounds__(256)
+tau_rayleigh_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int ntemp,
+        const int* __restrict__ gpoint_flavor, const F* __restrict__ krayl,
+        const int idx_h2o, const F* __restrict__ col_dry, const F* __restrict__ col_gas,
+        const F* __restrict__ fminor, const int* __restrict__ jeta, const Bool* __restrict__ tropo,
+        const int* __restrict__ jtemp, F* __restrict__ tau_rayleigh)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    if (icol >= ncol || ilay >= nlay) return;
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const int itropo = tropo[idx] ? 0 : 1;
+    const int jt = jtemp[idx];
+    const F fac = col_gas[idx + size_t(idx_h2o)*ncl] + col_dry[idx];
+    int cur_flav = -1;
+    F f[4]; int j0 = 1, j1 = 1;
+    for (int ig=0; ig<ngpt; ++ig)
+    {
+        const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
+        if (iflav != cur_flav)
+        {
+            cur_flav = iflav;
+            const size_t cell = idx + iflav*ncl;
+            #pragma unroll
+            for (int i=0; i<4; ++i) f[i] = fminor[4*cell + i];
+            j0 = jeta[2*cell]; j1 = jeta[2*cell+1];
+        }
+        const F* k = krayl + size_t(itropo)*ntemp*neta*ngpt + size_t(ig)*ntemp*neta;
+        const F kloc = f[0] * k[(jt-1) + (j0-1)*ntemp] + f[1] * k[(jt-1) + j0*ntemp] +
+                       f[2] * k[ jt    + (j1-1)*ntemp] + f[3] * k[ jt    + j1*ntemp];
+        tau_rayleigh[idx + size_t(ig)*ncl] = kloc * fac;
+    }
+}
+
+
+template<typename F>
+__global__ void combine_kernel(const size_t n, const F* __restrict__ tau_abs, const F* __restrict__ tau_ray,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+{
+    for (size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x)*blockDim.x)
+    {
+        const F r = tau_ray[i];
+        const F t = tau_abs[i] + r;
+        tau[i] = t;
+        ssa[i] = (t > F(2.)*Lim<F>::eps()) ? r / t : F(0.);
+        g[i] = F(0.);
+    }
+}
+
+
+// /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:2-13
+template<typename F>
+__device__ __forceinline__ F interp1d(const F val, const F offset, const F delta, const int len, const F* __restrict__ table)
+{
+    const F val0 = (val - offset)/delta;
+    const F frac = val0 - int(val0);
+    const int idx = min(len-1, max(1, int(val0)+1));
+    return table[idx-1] + frac * (table[idx] - table[idx-1]);
+}
+
+template<typename F>
+struct CellInterp
+{
+    F fm[8]; int je[2]; int jt, jp;
+    __device__ __forceinline__ void load(const size_t cell, const F* __restrict__ fmajor, const int* __restrict__ jeta)
+    {
+        #pragma unroll
+        for (int i=0; i<8; ++i) fm[i] = fmajor[8*cell + i];
+        je[0] = jeta[2*cell]; je[1] = jeta[2*cell+1];
+    }
+    __device__ __forceinline__ F pfrac(const F* __restrict__ p, const size_t s_eta, const size_t s_prs) const
+    {
+        return (fm[0] * p[(jt-1) + (je[0]-1)*s_eta + (jp-1)*s_prs]
+              + fm[1] * p[(jt-1) +  je[0]   *s_eta + (jp-1)*s_prs]
+              + fm[2] * p[(jt-1) + (je[0]-1)*s_eta +  jp   *s_prs]
+              + fm[3] * p[(jt-1) +  je[0]   *s_eta +  jp   *s_prs])
+             + (fm[4] * p[ jt    + (je[1]-1)*s_eta + (jp-1)*s_prs]
+              + fm[5] * p[ jt    +  je[1]   *s_eta + (jp-1)*s_prs]
+              + fm[6] * p[ jt    + (je[1]-1)*s_eta +  jp   *s_prs]
+              + fm[7] * p[ jt    +  je[1]   *s_eta +  jp   *s_prs]);
+    }
+};
+
+// /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:196-314
+template<typename F>
+__global__ void __launch_bounds__(256)
+planck_source_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp, const int nPlanckTemp,
+        const F* __restrict__ tlay, const F* __restrict__ tlev, const F* __restrict__ tsfc, const int sfc_lay,
+        const F* __restrict__ fmajor, const int* __restrict__ jeta, const Bool* __restrict__ tropo,
+        const int* __restrict__ jtemp, const int* __restrict__ jpress,
+        const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
+        const F temp_ref_min, const F totplnk_delta, const F* __restrict__ totplnk,
+        const int* __restrict__ gpoint_flavor,
+        F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    if (icol >= ncol || ilay >= nlay) return;
+
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t ncv = size_t(ncol)*(nlay+1);
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const size_t s_eta = ntemp, s_prs = size_t(ntemp)*neta, s_gpt = size_t(ntemp)*neta*(npres+1);
+    const F delta_Tsurf = F(1.);
+
+    const int itropo = tropo[idx] ? 0 : 1;
+    CellInterp<F> own, prev;
+    own.jt = jtemp[idx]; own.jp = jpress[idx] + itropo;
+    int itropo_m1 = 0;
+    const bool has_prev = ilay > 0;
+    if (has_prev)
+    {
+        itropo_m1 = tropo[idx - ncol] ? 0 : 1;
+        prev.jt = jtemp[idx - ncol]; prev.jp = jpress[idx - ncol] + itropo_m1;
+    }
+    const F t_lay = tlay[idx], t_lev = tlev[idx];
+    const bool is_last = ilay == nlay-1;
+    const bool is_sfc = ilay == sfc_lay-1;
+    const F t_levp = is_last ? tlev[idx + ncol] : F(0.);
+    const F t_sfc = is_sfc ? tsfc[icol] : F(0.);
+
+    int cur_flav = -1, cur_flav_m1 = -1, cur_bnd = -1;
+    F b_lay = 0, b_lev = 0, b_levp = 0, b_sfc = 0, b_sfc2 = 0;
+
+    for (int ig=0; ig<ngpt; ++ig)
+    {
+        const int ibnd = gpoint_bands[ig] - 1;
+        if (ibnd != cur_bnd)
+        {
+            cur_bnd = ibnd;
+            const F* tp = totplnk + size_t(ibnd)*nPlanckTemp;
+            b_lay = interp1d(t_lay, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+            b_lev = interp1d(t_lev, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+            if (is_last) b_levp = interp1d(t_levp, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+            if (is_sfc)
+            {
+                b_sfc  = interp1d(t_sfc              , temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                b_sfc2 = interp1d(t_sfc + delta_Tsurf, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+            }
+        }
+        const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
+        if (iflav != cur_flav) { cur_flav = iflav; own.load(idx + iflav*ncl, fmajor, jeta); }
+        const F* p = pfracin + size_t(ig)*s_gpt;
+        const F pfrac = own.pfrac(p, s_eta, s_prs);
+
+        lay_src[idx + size_t(ig)*ncl] = pfrac * b_lay;
+
+        F lev_val = pfrac * b_lev;
+        if (has_prev)
+        {
+            const int iflav_m1 = gpoint_flavor[itropo_m1 + 2*ig] - 1;
+            if (iflav_m1 != cur_flav_m1) { cur_flav_m1 = iflav_m1; prev.load(idx - ncol + iflav_m1*ncl, fmajor, jeta); }
+            lev_val = sqrt(pfrac * prev.pfrac(p, s_eta, s_prs)) * b_lev;
+        }
+        lev_src[idx + size_t(ig)*ncv] = lev_val;
+        if (is_last) lev_src[idx + ncol + size_t(ig)*ncv] = pfrac * b_levp;
+        if (is_sfc)
+        {
+            sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
+            sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
+        }
+    }
+}
+
+
+template<typename F>
+__global__ void reorder123x321_kernel(const int ni, const int nj, const int nk, const F* __restrict__ in, F* __restrict__ out)
+{
+    const size_t n = size_t(ni)*nj*nk;
+    for (size_t o = size_t(blockIdx.x)*blockDim.x + threadIdx.x; o < n; o += size_t(gridDim.x)*blockDim.x)
+    {
+        const int ii = int(o % ni), ij = int((o / ni) % nj), ik = int(o / (size_t(ni)*nj));
+        out[o] = in[ik + size_t(ij)*nk + size_t(ii)*nj*nk];
+    }
+}
+
+template<typename F>
+__global__ void reorder12x21_kernel(const int ni, const int nj, const F* __restrict__ in, F* __restrict__ out)
+{
+    const size_t n = size_t(ni)*nj;
+    for (size_t o = size_t(blockIdx.x)*blockDim.x + threadIdx.x; o < n; o += size_t(gridDim.x)*blockDim.x)
+    {
+        const int ii = int(o % ni), ij = int(o / ni);
+        out[o] = in[ij + size_t(ii)*nj];
+    }
+}
+
+inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*8)); }
+
+template<typename F, int MODE>
+int tau_absorption_impl(
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp,
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o,
+        const int* gpoint_flavor, const int* band_lims_gpt,
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper,
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+        const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+        const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+        const int* idx_minor_lower, const int* idx_minor_upper,
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper,
+        const int* kminor_start_lower, const int* kminor_start_upper,
+        const Bool* tropo, const F* col_mix, const F* fmajor, const F* fminor,
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry,
+        const int* jeta, const int* jtemp, const int* jpress, const F* krayl,
+        F* tau, F* ssa, F* g, void* stream, const char* name)
+{
+    RRX_TRY
+    (void)nband; (void)ngas; (void)nflav; (void)band_lims_gpt; (void)nminorklower; (void)nminorkupper;
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const int nmax = std::max(nminorlower, nminorupper);
+    const size_t lds = size_t(2)*nchunk*(1 + nmax)*sizeof(int);
+    if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
+    const dim3 block(64, 4);
+    const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
+    tau_absorption_kernel<F,MODE><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(
+            ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+            minor_scales_with_density_lower, minor_scales_with_density_upper,
+            scale_by_complement_lower, scale_by_complement_upper,
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+            kminor_start_lower, kminor_start_upper,
+            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
+            tau, ssa, g);
+    RRX_CATCH(name)
+}
+}  // namespace
+
+
+extern "C"
+{
+#define RRX_DEFINE_GAS(F, SFX) \
+int rrx_interpolation##SFX( \
+        int ncol, int nlay, int ngas, int nflav, int neta, int npres, int ntemp, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, \
+        const F* vmr_ref, const F* play, const F* tlay, F* col_gas, \
+        int* jtemp, F* fmajor, F* fminor, F* col_mix, RrxBool* tropo, int* jeta, int* jpress, void* stream) \
+{ \
+    RRX_TRY \
+    if (ncol <= 0 || nlay <= 0) throw std::runtime_error("empty problem"); \
+    interpolation_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, 4)), dim3(64, 4), 0, static_cast<hipStream_t>(stream)>>>( \
+            ncol, nlay, ngas, nflav, neta, npres, ntemp, flavor, press_ref_log, temp_ref, \
+            press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref, play, tlay, col_gas, \
+            jtemp, fmajor, fminor, col_mix, tropo, jeta, jpress); \
+    RRX_CATCH("rrx_interpolation") \
+} \
+int rrx_compute_tau_absorption##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const RrxBool* tropo, const F* col_mix, const F* fmajor, const F* fminor, \
+        const F* play, const F* tlay, const F* col_gas, \
+        const int* jeta, const int* jtemp, const int* jpress, F* tau, void* stream) \
+{ \
+    return tau_absorption_impl<F,0>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, (const F*)nullptr, jeta, jtemp, jpress, (const F*)nullptr, \
+            tau, (F*)nullptr, (F*)nullptr, stream, "rrx_compute_tau_absorption"); \
+} \
+int rrx_gas_optics_sw_fused##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const RrxBool* tropo, const F* col_mix, const F* fmajor, const F* fminor, \
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry, \
+        const int* jeta, const int* jtemp, const int* jpress, const F* krayl, \
+        F* tau, F* ssa, F* g, void* stream) \
+{ \
+    return tau_absorption_impl<F,1>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl, \
+            tau, ssa, g, stream, "rrx_gas_optics_sw_fused"); \
+} \
+int rrx_compute_tau_rayleigh##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        const int* gpoint_flavor, const int* band_lims_gpt, const F* krayl, \
+        int idx_h2o, const F* col_dry, const F* col_gas, \
+        const F* fminor, const int* jeta, const RrxBool* tropo, const int* jtemp, F* tau_rayleigh, void* stream) \
+{ \
+    RRX_TRY \
+    (void)nbnd; (void)ngas; (void)nflav; (void)npres; (void)band_lims_gpt; \
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
+    tau_rayleigh_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, 4)), dim3(64, 4), 0, static_cast<hipStream_t>(stream)>>>( \
+            ncol, nlay, ngpt, neta, ntemp, gpoint_flavor, krayl, idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_rayleigh); \
+    RRX_CATCH("rrx_compute_tau_rayleigh") \
+} \
+int rrx_combine_abs_and_rayleigh##SFX(int ncol, int nlay, int ngpt, const F* tau_abs, const F* tau_rayleigh, F* tau, F* ssa, F* g, void* stream) \
+{ \
+    RRX_TRY \
+    const size_t n = size_t(ncol)*nlay*ngpt; \
+    combine_kernel<F><<<grid1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, tau_abs, tau_rayleigh, tau, ssa, g); \
+    RRX_CATCH("rrx_combine_abs_and_rayleigh") \
+} \
+int rrx_compute_planck_source##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, \
+        const F* fmajor, const int* jeta, const RrxBool* tropo, const int* jtemp, const int* jpress, \
+        const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
+        F temp_ref_min, F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
+        F* sfc_src, F* lay_src, F* lev_src, F* sfc_src_jac, void* stream) \
+{ \
+    RRX_TRY \
+    (void)nbnd; (void)nflav; (void)band_lims_gpt; \
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
+    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, 4)), dim3(64, 4), 0, static_cast<hipStream_t>(stream)>>>( \
+            ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
+            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac); \
+    RRX_CATCH("rrx_compute_planck_source") \
+} \
+int rrx_reorder123x321##SFX(int ni, int nj, int nk, const F* arr_in, F* arr_out, void* stream) \
+{ \
+    RRX_TRY \
+    reorder123x321_kernel<F><<<grid1d(size_t(ni)*nj*nk), 256, 0, static_cast<hipStream_t>(stream)>>>(ni, nj, nk, arr_in, arr_out); \
+    RRX_CATCH("rrx_reorder123x321") \
+} \
+int rrx_reorder12x21##SFX(int ni, int nj, const F* arr_in, F* arr_out, void* stream) \
+{ \
+    RRX_TRY \
+    reorder12x21_kernel<F><<<grid1d(size_t(ni)*nj), 256, 0, static_cast<hipStream_t>(stream)>>>(ni, nj, arr_in, arr_out); \
+    RRX_CATCH("rrx_reorder12x21") \
+} \
+int rrx_zero_array##SFX(int ni, int nj, int nk, F* arr, void* stream) \
+{ \
+    RRX_TRY \
+    if (hipMemsetAsync(arr, 0, size_t(ni)*nj*nk*sizeof(F), static_cast<hipStream_t>(stream)) != hipSuccess) \
+        throw std::runtime_error("hipMemsetAsync failed"); \
+    RRX_CATCH("rrx_zero_array") \
+}
+
+RRX_DEFINE_GAS(double, _f64)
+RRX_DEFINE_GAS(float, _f32)
+}

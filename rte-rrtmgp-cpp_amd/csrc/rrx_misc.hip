@@ -1,0 +1,381 @@
+// Element-wise / reduction / gather kernels of the hot path and the small runtime of librrx_hip.so.
+// Replaces Optical_props_kernels_cuda::*, Fluxes_kernels_cuda::*, Subset_kernels_cuda::* and the inline kernels of
+// src_cuda/{Gas_optics_rrtmgp,Rte_lw,Rte_sw,Cloud_optics}.cu and include/Array.h (file:line per function in
+// include/rrx_hip.h). All of these are pure HBM-bandwidth work: every kernel keeps the column index on the lanes
+// (the reference's optical-props launchers put the g-point on threadIdx.x, i.e. strided by ncol*nlay) and moves
+// 16 B per lane where the alignment allows.
+#include <mutex>
+#include "rrx_common.h"
+#include "rrx_hip.h"
+
+namespace rrx
+{
+    static thread_local std::string g_last_error;
+    void set_error(const std::string& msg) { g_last_error = msg; }
+    int check_launch(const char* what)
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+            set_error(std::string(what) + ": " + hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
+    }
+}
+
+namespace
+{
+using namespace rrx;
+
+inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*16)); }
+#define RRX_GRID_STRIDE(i, n) for (size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x; i < (n); i += size_t(gridDim.x)*blockDim.x)
+
+// ---- optical props: /root/reference/src_kernels_cuda/optical_props_kernels.cu:31-161 ----
+template<typename F>
+__global__ void inc_1scl_kernel(const size_t n, F* __restrict__ tau1, const F* __restrict__ tau2)
+{
+    RRX_GRID_STRIDE(i, n) tau1[i] = tau1[i] + tau2[i];
+}
+
+template<typename F>
+__device__ __forceinline__ void inc_2str(F& tau1, F& ssa1, F& g1, const F tau2, const F ssa2, const F g2, const F eps)
+{
+    const F tau12 = tau1 + tau2;
+    const F tauscat12 = (tau1 * ssa1) + (tau2 * ssa2);
+    g1 = ((tau1 * ssa1 * g1) + (tau2 * ssa2 * g2)) / max(tauscat12, eps);
+    ssa1 = tauscat12 / max(eps, tau12);
+    tau1 = tau12;
+}
+
+template<typename F>
+__global__ void inc_2str_kernel(const size_t n, const F eps, F* __restrict__ tau1, F* __restrict__ ssa1, F* __restrict__ g1,
+        const F* __restrict__ tau2, const F* __restrict__ ssa2, const F* __restrict__ g2)
+{
+    RRX_GRID_STRIDE(i, n)
+    {
+        F t = tau1[i], w = ssa1[i], gg = g1[i];
+        inc_2str(t, w, gg, tau2[i], ssa2[i], g2[i], eps);
+        tau1[i] = t; ssa1[i] = w; g1[i] = gg;
+    }
+}
+
+// g-point -> band map resolved once per block row (blockIdx.y = g-point), cells on the lanes
+template<typename F>
+__global__ void inc_1scl_bybnd_kernel(const size_t ncl, F* __restrict__ tau1, const F* __restrict__ tau2,
+        const int nbnd, const int* __restrict__ band_lims_gpt)
+{
+    const int igpt = blockIdx.y;
+    for (int ibnd=0; ibnd<nbnd; ++ibnd)
+        if (igpt+1 >= band_lims_gpt[2*ibnd] && igpt+1 <= band_lims_gpt[2*ibnd+1])
+        {
+            RRX_GRID_STRIDE(i, ncl) tau1[i + igpt*ncl] = tau1[i + igpt*ncl] + tau2[i + ibnd*ncl];
+        }
+}
+
+template<typename F>
+__global__ void inc_2str_bybnd_kernel(const size_t ncl, const F eps, F* __restrict__ tau1, F* __restrict__ ssa1, F* __restrict__ g1,
+        const F* __restrict__ tau2, const F* __restrict__ ssa2, const F* __restrict__ g2,
+        const int nbnd, const int* __restrict__ band_lims_gpt)
+{
+    const int igpt = blockIdx.y;
+    for (int ibnd=0; ibnd<nbnd; ++ibnd)
+        if (igpt+1 >= band_lims_gpt[2*ibnd] && igpt+1 <= band_lims_gpt[2*ibnd+1])
+        {
+            RRX_GRID_STRIDE(i, ncl)
+            {
+                const size_t o = i + igpt*ncl, b = i + ibnd*ncl;
+                F t = tau1[o], w = ssa1[o], gg = g1[o];
+                inc_2str(t, w, gg, tau2[b], ssa2[b], g2[b], eps);
+                tau1[o] = t; ssa1[o] = w; g1[o] = gg;
+            }
+        }
+}
+
+template<typename F>
+__global__ void delta_scale_kernel(const size_t n, const F eps, F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+{
+    RRX_GRID_STRIDE(i, n)
+    {
+        const F gv = g[i], wv = ssa[i];
+        const F f = gv * gv;
+        const F wf = wv * f;
+        tau[i] *= (F(1.) - wf);
+        ssa[i] = (wv - wf) / max(eps, F(1.) - wf);
+        g[i] = (gv - f) / max(eps, F(1.) - f);
+    }
+}
+
+// ---- fluxes: /root/reference/src_kernels_cuda/fluxes_kernels.cu:27-62; by-band: mo_fluxes_byband_kernels.F90 ----
+template<typename F>
+__global__ void sum_broadband_kernel(const size_t nlc, const int ngpt, const F* __restrict__ in, F* __restrict__ out)
+{
+    RRX_GRID_STRIDE(i, nlc)
+    {
+        F s = F(0.);
+        for (int ig=0; ig<ngpt; ++ig) s += in[i + size_t(ig)*nlc];
+        out[i] = s;
+    }
+}
+
+template<typename F>
+__global__ void net_kernel(const size_t n, const F* __restrict__ dn, const F* __restrict__ up, F* __restrict__ net)
+{
+    RRX_GRID_STRIDE(i, n) net[i] = dn[i] - up[i];
+}
+
+template<typename F, bool NET>
+__global__ void byband_kernel(const size_t nlc, const int* __restrict__ band_lims, const F* __restrict__ a, const F* __restrict__ b, F* __restrict__ out)
+{
+    const int ibnd = blockIdx.y;
+    const int g0 = band_lims[2*ibnd]-1, g1 = band_lims[2*ibnd+1]-1;
+    RRX_GRID_STRIDE(i, nlc)
+    {
+        F s = NET ? a[i + size_t(g0)*nlc] - b[i + size_t(g0)*nlc] : a[i + size_t(g0)*nlc];
+        for (int ig=g0+1; ig<=g1; ++ig)
+            s += NET ? a[i + size_t(ig)*nlc] - b[i + size_t(ig)*nlc] : a[i + size_t(ig)*nlc];
+        out[i + size_t(ibnd)*nlc] = s;
+    }
+}
+
+// ---- subset scatter: /root/reference/src_kernels_cuda/subset_kernels.cu:2-98 ----
+template<typename F> struct PtrPack { F* full[4]; const F* sub[4]; };
+
+template<typename F>
+__global__ void get_from_subset_kernel(const int ncol, const size_t nrest, const int ncol_in, const int col_s_in, const int narr, const PtrPack<F> p)
+{
+    const size_t n = size_t(ncol_in)*nrest;
+    RRX_GRID_STRIDE(i, n)
+    {
+        const size_t ic = i % ncol_in, r = i / ncol_in;
+        const size_t o = ic + col_s_in - 1 + r*ncol;
+        for (int a=0; a<narr; ++a) p.full[a][o] = p.sub[a][i];
+    }
+}
+
+// ---- host-class helper kernels ----
+template<typename F>
+__global__ void fill_gases_kernel(const int ncol, const int nlay, const int dim1, const int dim2, const int igas,
+        F* __restrict__ vmr_out, const F* __restrict__ vmr_in, F* __restrict__ col_gas, const F* __restrict__ col_dry)
+{
+    const size_t ncl = size_t(ncol)*nlay;
+    RRX_GRID_STRIDE(i, ncl)
+    {
+        if (igas > 0)
+        {
+            F v;
+            if (dim1 == 1 && dim2 == 1) v = vmr_in[0];
+            else if (dim1 == 1)         v = vmr_in[i / ncol];
+            else                        v = vmr_in[i];
+            vmr_out[i + size_t(igas-1)*ncl] = v;
+            col_gas[i + size_t(igas)*ncl] = v * col_dry[i];
+        }
+        else
+            col_gas[i] = col_dry[i];
+    }
+}
+
+template<typename F>
+__global__ void col_dry_kernel(const int ncol, const int nlay, const F* __restrict__ vmr_h2o, const F* __restrict__ plev, F* __restrict__ col_dry)
+{
+    constexpr F g0 = 9.80665;
+    constexpr F avogad = 6.02214076e23;
+    constexpr F m_dry = 0.028964;
+    constexpr F m_h2o = 0.018016;
+    const size_t ncl = size_t(ncol)*nlay;
+    RRX_GRID_STRIDE(i, ncl)
+    {
+        const F delta_plev = abs(plev[i] - plev[i + ncol]);
+        const F h = vmr_h2o[i];
+        const F m_air = (m_dry + m_h2o * h) / (F(1.) + h);
+        F cd = F(10.) * delta_plev * avogad / (F(1000.)*m_air*F(100.)*g0);
+        cd /= (F(1.) + h);
+        col_dry[i] = cd;
+    }
+}
+
+template<typename F>
+__global__ void expand_and_transpose_kernel(const int ncol, const int nbnd, const int* __restrict__ limits, const F* __restrict__ in, F* __restrict__ out)
+{
+    const int ibnd = blockIdx.y;
+    const int g0 = limits[2*ibnd]-1, g1 = limits[2*ibnd+1];
+    RRX_GRID_STRIDE(icol, size_t(ncol))
+    {
+        const F v = in[ibnd + icol*nbnd];
+        for (int ig=g0; ig<g1; ++ig) out[icol + size_t(ig)*ncol] = v;
+    }
+}
+
+template<typename F>
+__global__ void spread_col_kernel(const int ncol, const int ngpt, F* __restrict__ out, const F* __restrict__ src)
+{
+    const size_t n = size_t(ncol)*ngpt;
+    RRX_GRID_STRIDE(i, n) out[i] = src[i / ncol];
+}
+
+template<typename F>
+__global__ void scale_cols_kernel(const int ncol, const int ngpt, F* __restrict__ out, const F* __restrict__ fac)
+{
+    const size_t n = size_t(ncol)*ngpt;
+    RRX_GRID_STRIDE(i, n) out[i] *= fac[i % ncol];
+}
+
+// /root/reference/src/Cloud_optics.cpp:72-107 (and src_cuda/Cloud_optics.cu:31-70)
+template<typename F>
+__device__ __forceinline__ void cloud_from_table(const F cwp, const F re, const int nsteps, const F step_size, const F offset,
+        const F* __restrict__ tau_table, const F* __restrict__ ssa_table, const F* __restrict__ asy_table,
+        F& tau, F& taussa, F& taussag)
+{
+    if (cwp > F(0.))
+    {
+        const int index = min(int((re - offset) / step_size)+1, nsteps-1);
+        const F fint = (re - offset) / step_size - (index-1);
+        tau = cwp * (tau_table[index-1] + fint * (tau_table[index] - tau_table[index-1]));
+        taussa = tau * (ssa_table[index-1] + fint * (ssa_table[index] - ssa_table[index-1]));
+        taussag = taussa * (asy_table[index-1] + fint * (asy_table[index] - asy_table[index-1]));
+    }
+    else { tau = F(0.); taussa = F(0.); taussag = F(0.); }
+}
+
+template<typename F, bool TWOSTR>
+__global__ void cloud_optics_kernel(const size_t ncl, const int nsize_liq, const int nsize_ice,
+        const F radliq_lwr, const F liq_step, const F diamice_lwr, const F ice_step,
+        const F* __restrict__ lut_extliq, const F* __restrict__ lut_ssaliq, const F* __restrict__ lut_asyliq,
+        const F* __restrict__ lut_extice, const F* __restrict__ lut_ssaice, const F* __restrict__ lut_asyice,
+        const F* __restrict__ clwp, const F* __restrict__ ciwp, const F* __restrict__ reliq, const F* __restrict__ deice,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+{
+    const int ibnd = blockIdx.y;
+    const F eps = Lim<F>::eps();
+    RRX_GRID_STRIDE(i, ncl)
+    {
+        F lt, lts, ltsg, it, its, itsg;
+        cloud_from_table(clwp[i], reliq[i], nsize_liq, liq_step, radliq_lwr,
+                lut_extliq + size_t(ibnd)*nsize_liq, lut_ssaliq + size_t(ibnd)*nsize_liq, lut_asyliq + size_t(ibnd)*nsize_liq, lt, lts, ltsg);
+        cloud_from_table(ciwp[i], deice[i], nsize_ice, ice_step, diamice_lwr,
+                lut_extice + size_t(ibnd)*nsize_ice, lut_ssaice + size_t(ibnd)*nsize_ice, lut_asyice + size_t(ibnd)*nsize_ice, it, its, itsg);
+        const size_t o = i + size_t(ibnd)*ncl;
+        if constexpr (TWOSTR)
+        {
+            const F t = lt + it, ts = lts + its, tsg = ltsg + itsg;
+            tau[o] = t;
+            ssa[o] = ts / max(t, eps);
+            g[o] = tsg / max(ts, eps);
+        }
+        else
+            tau[o] = (lt - lts) + (it - its);
+    }
+}
+
+template<typename F>
+__global__ void subset_cols_kernel(const int ncol_full, const size_t nrest, const int col_s, const int ncol_sub, const F* __restrict__ in, F* __restrict__ out)
+{
+    const size_t n = size_t(ncol_sub)*nrest;
+    RRX_GRID_STRIDE(i, n)
+    {
+        const size_t ic = i % ncol_sub, r = i / ncol_sub;
+        out[i] = in[ic + col_s - 1 + r*ncol_full];
+    }
+}
+
+template<typename F>
+__global__ void fill_kernel(const size_t n, const F v, F* __restrict__ a)
+{
+    RRX_GRID_STRIDE(i, n) a[i] = v;
+}
+}  // namespace
+
+
+extern "C"
+{
+const char* rrx_last_error(void) { return rrx::g_last_error.c_str(); }
+
+#define RRX_HIP_OK(call, name) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    rrx::set_error(std::string(name) + ": " + hipGetErrorString(e_)); return 2; } } while (0)
+
+int rrx_device_count(int* n) { RRX_HIP_OK(hipGetDeviceCount(n), "rrx_device_count"); return 0; }
+int rrx_set_device(int dev) { RRX_HIP_OK(hipSetDevice(dev), "rrx_set_device"); return 0; }
+int rrx_malloc(void** ptr, unsigned long long bytes) { RRX_HIP_OK(hipMalloc(ptr, bytes ? bytes : 1), "rrx_malloc"); return 0; }
+int rrx_free(void* ptr) { RRX_HIP_OK(hipFree(ptr), "rrx_free"); return 0; }
+int rrx_memcpy_h2d(void* dst, const void* src, unsigned long long bytes) { RRX_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "rrx_memcpy_h2d"); return 0; }
+int rrx_memcpy_d2h(void* dst, const void* src, unsigned long long bytes) { RRX_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "rrx_memcpy_d2h"); return 0; }
+int rrx_memcpy_d2d(void* dst, const void* src, unsigned long long bytes, void* stream) { RRX_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)), "rrx_memcpy_d2d"); return 0; }
+int rrx_memset(void* dst, int value, unsigned long long bytes, void* stream) { RRX_HIP_OK(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)), "rrx_memset"); return 0; }
+int rrx_synchronize(void* stream) { RRX_HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "rrx_synchronize"); return 0; }
+int rrx_stream_create(void** stream) { hipStream_t s; RRX_HIP_OK(hipStreamCreate(&s), "rrx_stream_create"); *stream = s; return 0; }
+int rrx_stream_destroy(void* stream) { RRX_HIP_OK(hipStreamDestroy(static_cast<hipStream_t>(stream)), "rrx_stream_destroy"); return 0; }
+
+#define ST static_cast<hipStream_t>(stream)
+
+#define RRX_DEFINE_MISC(F, SFX) \
+int rrx_increment_1scalar_by_1scalar##SFX(int ncol, int nlay, int ngpt, F* tau_inout, const F* tau_in, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlay*ngpt; \
+  inc_1scl_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, tau_inout, tau_in); RRX_CATCH("rrx_increment_1scalar_by_1scalar") } \
+int rrx_increment_2stream_by_2stream##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* ssa_inout, F* g_inout, const F* tau_in, const F* ssa_in, const F* g_in, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlay*ngpt; \
+  inc_2str_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, rrx::Lim<F>::tiny()*F(3.), tau_inout, ssa_inout, g_inout, tau_in, ssa_in, g_in); RRX_CATCH("rrx_increment_2stream_by_2stream") } \
+int rrx_inc_1scalar_by_1scalar_bybnd##SFX(int ncol, int nlay, int ngpt, F* tau_inout, const F* tau_in, int nbnd, const int* band_lims_gpoint, void* stream) \
+{ RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
+  inc_1scl_bybnd_kernel<F><<<dim3(std::min(grid1d(ncl), 1024), ngpt), 256, 0, ST>>>(ncl, tau_inout, tau_in, nbnd, band_lims_gpoint); RRX_CATCH("rrx_inc_1scalar_by_1scalar_bybnd") } \
+int rrx_inc_2stream_by_2stream_bybnd##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* ssa_inout, F* g_inout, const F* tau_in, const F* ssa_in, const F* g_in, int nbnd, const int* band_lims_gpoint, void* stream) \
+{ RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
+  inc_2str_bybnd_kernel<F><<<dim3(std::min(grid1d(ncl), 1024), ngpt), 256, 0, ST>>>(ncl, rrx::Lim<F>::tiny()*F(3.), tau_inout, ssa_inout, g_inout, tau_in, ssa_in, g_in, nbnd, band_lims_gpoint); RRX_CATCH("rrx_inc_2stream_by_2stream_bybnd") } \
+int rrx_delta_scale_2str_k##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* ssa_inout, F* g_inout, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlay*ngpt; \
+  delta_scale_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, rrx::Lim<F>::tiny()*F(3.), tau_inout, ssa_inout, g_inout); RRX_CATCH("rrx_delta_scale_2str_k") } \
+int rrx_sum_broadband##SFX(int ncol, int nlev, int ngpt, const F* gpt_flux, F* flux, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlev; \
+  sum_broadband_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, ngpt, gpt_flux, flux); RRX_CATCH("rrx_sum_broadband") } \
+int rrx_net_broadband_precalc##SFX(int ncol, int nlev, const F* flux_dn, const F* flux_up, F* flux_net, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlev; \
+  net_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, flux_dn, flux_up, flux_net); RRX_CATCH("rrx_net_broadband_precalc") } \
+int rrx_sum_byband##SFX(int ncol, int nlev, int ngpt, int nbnd, const int* band_lims, const F* gpt_flux, F* bnd_flux, void* stream) \
+{ RRX_TRY (void)ngpt; const size_t n = size_t(ncol)*nlev; \
+  byband_kernel<F,false><<<dim3(std::min(grid1d(n), 1024), nbnd), 256, 0, ST>>>(n, band_lims, gpt_flux, (const F*)nullptr, bnd_flux); RRX_CATCH("rrx_sum_byband") } \
+int rrx_net_byband_full##SFX(int ncol, int nlev, int ngpt, int nbnd, const int* band_lims, const F* gpt_flux_dn, const F* gpt_flux_up, F* bnd_flux_net, void* stream) \
+{ RRX_TRY (void)ngpt; const size_t n = size_t(ncol)*nlev; \
+  byband_kernel<F,true><<<dim3(std::min(grid1d(n), 1024), nbnd), 256, 0, ST>>>(n, band_lims, gpt_flux_dn, gpt_flux_up, bnd_flux_net); RRX_CATCH("rrx_net_byband_full") } \
+int rrx_get_from_subset##SFX(int ncol, int nlay, int nbnd, int ncol_in, int col_s_in, int narr, F* const* var_full, const F* const* var_sub, void* stream) \
+{ RRX_TRY if (narr < 1 || narr > 4) throw std::runtime_error("narr must be 1..4"); \
+  if (col_s_in < 1 || col_s_in - 1 + ncol_in > ncol) throw std::runtime_error("column range outside the full array"); \
+  PtrPack<F> p; for (int a=0; a<narr; ++a) { p.full[a] = var_full[a]; p.sub[a] = var_sub[a]; } \
+  const size_t nrest = size_t(nlay)*nbnd; \
+  get_from_subset_kernel<F><<<grid1d(size_t(ncol_in)*nrest), 256, 0, ST>>>(ncol, nrest, ncol_in, col_s_in, narr, p); RRX_CATCH("rrx_get_from_subset") } \
+int rrx_fill_gases##SFX(int ncol, int nlay, int dim1, int dim2, int ngas, int igas, F* vmr_out, const F* vmr_in, F* col_gas, const F* col_dry, void* stream) \
+{ RRX_TRY (void)ngas; fill_gases_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, dim1, dim2, igas, vmr_out, vmr_in, col_gas, col_dry); RRX_CATCH("rrx_fill_gases") } \
+int rrx_get_col_dry##SFX(int ncol, int nlay, const F* vmr_h2o, const F* plev, F* col_dry, void* stream) \
+{ RRX_TRY col_dry_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, vmr_h2o, plev, col_dry); RRX_CATCH("rrx_get_col_dry") } \
+int rrx_expand_and_transpose##SFX(int ncol, int nbnd, const int* band_lims_gpt, const F* arr_in, F* arr_out, void* stream) \
+{ RRX_TRY expand_and_transpose_kernel<F><<<dim3(std::min(grid1d(ncol), 1024), nbnd), 256, 0, ST>>>(ncol, nbnd, band_lims_gpt, arr_in, arr_out); RRX_CATCH("rrx_expand_and_transpose") } \
+int rrx_spread_col##SFX(int ncol, int ngpt, F* toa_src, const F* solar_source, void* stream) \
+{ RRX_TRY spread_col_kernel<F><<<grid1d(size_t(ncol)*ngpt), 256, 0, ST>>>(ncol, ngpt, toa_src, solar_source); RRX_CATCH("rrx_spread_col") } \
+int rrx_scaling_to_subset##SFX(int ncol, int ngpt, F* toa_src, const F* tsi_scaling, void* stream) \
+{ RRX_TRY scale_cols_kernel<F><<<grid1d(size_t(ncol)*ngpt), 256, 0, ST>>>(ncol, ngpt, toa_src, tsi_scaling); RRX_CATCH("rrx_scaling_to_subset") } \
+int rrx_cloud_optics_2str##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
+        F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
+        const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
+        const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, F* ssa, F* g, void* stream) \
+{ RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
+  cloud_optics_kernel<F,true><<<dim3(std::min(grid1d(ncl), 1024), nbnd), 256, 0, ST>>>(ncl, nsize_liq, nsize_ice, \
+      radliq_lwr, (radliq_upr - radliq_lwr)/(nsize_liq - F(1.)), diamice_lwr, (diamice_upr - diamice_lwr)/(nsize_ice - F(1.)), \
+      lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice, clwp, ciwp, reliq, deice, tau, ssa, g); RRX_CATCH("rrx_cloud_optics_2str") } \
+int rrx_cloud_optics_1scl##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
+        F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
+        const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
+        const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, void* stream) \
+{ RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
+  cloud_optics_kernel<F,false><<<dim3(std::min(grid1d(ncl), 1024), nbnd), 256, 0, ST>>>(ncl, nsize_liq, nsize_ice, \
+      radliq_lwr, (radliq_upr - radliq_lwr)/(nsize_liq - F(1.)), diamice_lwr, (diamice_upr - diamice_lwr)/(nsize_ice - F(1.)), \
+      lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice, clwp, ciwp, reliq, deice, tau, (F*)nullptr, (F*)nullptr); RRX_CATCH("rrx_cloud_optics_1scl") } \
+int rrx_subset_cols##SFX(int ncol_full, int nrest, int col_s, int ncol_sub, const F* in, F* out, void* stream) \
+{ RRX_TRY if (col_s < 1 || col_s - 1 + ncol_sub > ncol_full) throw std::runtime_error("column range outside the full array"); \
+  subset_cols_kernel<F><<<grid1d(size_t(ncol_sub)*nrest), 256, 0, ST>>>(ncol_full, size_t(nrest), col_s, ncol_sub, in, out); RRX_CATCH("rrx_subset_cols") } \
+int rrx_subset_lastdim##SFX(int n1, int col_s, int ncol_sub, const F* in, F* out, void* stream) \
+{ RRX_TRY if (hipMemcpyAsync(out, in + size_t(col_s-1)*n1, size_t(n1)*ncol_sub*sizeof(F), hipMemcpyDeviceToDevice, ST) != hipSuccess) \
+      throw std::runtime_error("hipMemcpyAsync failed"); RRX_CATCH("rrx_subset_lastdim") } \
+int rrx_fill##SFX(unsigned long long n, F value, F* arr, void* stream) \
+{ RRX_TRY fill_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, value, arr); RRX_CATCH("rrx_fill") }
+
+RRX_DEFINE_MISC(double, _f64)
+RRX_DEFINE_MISC(float, _f32)
+}

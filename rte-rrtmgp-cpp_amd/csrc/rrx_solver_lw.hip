@@ -1,0 +1,476 @@
+// Longwave no-scattering solver, fused (boundary condition + source + both transport sweeps + quadrature
+// scaling in ONE kernel, no global scratch). Replaces the reference's launcher
+//   Rte_solver_kernels_cuda::lw_solver_noscat   (/root/reference/src_kernels_cuda/rte_solver_kernels_launchers.cu:61-286)
+// and its kernels lw_solver_noscat_step_{1,2,3}_kernel, lw_transport_noscat_kernel, apply_BC_kernel
+// (/root/reference/src_kernels_cuda/rte_solver_kernels.cu:35-193,351-387).
+//
+// MI355X design (DESIGN.md section "lw_solver_noscat"):
+//   * arrays are (col, lay, gpt) with the column index fastest. One wavefront owns a tile of 8*V columns x all
+//     levels of one g-point. The 64 lanes are 8 column-lanes x 8 level-lanes: lane = ll*8 + cl.
+//   * level-lane ll owns K consecutive levels/layers (in top-to-surface "sweep" order), held in registers.
+//     Every input is read exactly once from HBM, every output written exactly once.
+//   * the serial vertical recurrences x' = t*x + s are affine maps; each lane composes its K maps, an 8-lane
+//     Hillis-Steele scan (3 __shfl steps, stride 8 lanes) propagates the boundary values between level-lanes,
+//     and each lane then replays its K layers from its incoming value.
+#include "rrx_common.h"
+#include "rrx_hip.h"
+
+namespace
+{
+using namespace rrx;
+
+constexpr int CL = 8;    // column lanes
+constexpr int LL = 8;    // level lanes
+
+template<typename F, int V, int K, bool JAC, bool ACC>
+__global__ void __launch_bounds__(256)
+lw_noscat_scan_kernel(
+        const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
+        const F* __restrict__ secants, const F* __restrict__ weights,
+        const F* __restrict__ tau, const F* __restrict__ lay_source, const F* __restrict__ lev_source,
+        const F* __restrict__ sfc_emis, const F* __restrict__ sfc_src, const F* __restrict__ inc_flux,
+        F* __restrict__ flux_up, F* __restrict__ flux_dn,
+        const F* __restrict__ sfc_src_jac, F* __restrict__ flux_up_jac)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cl = lane & (CL-1);
+    const int ll = lane >> 3;
+    const int igpt = blockIdx.y;
+    const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    if (wave_col0 >= ncol) return;                    // wave-uniform
+
+    int icol = wave_col0 + cl*V;
+    int nvalid = ncol - icol;                         // columns this lane really owns
+    const bool active = nvalid > 0;
+    if (!active) { icol = wave_col0; nvalid = 1; }    // harmless duplicate loads, no stores
+    if (nvalid > V) nvalid = V;
+    const int nld = active ? nvalid : 1;
+
+    const int nlev = nlay + 1;
+    const size_t ncl = size_t(ncol);
+    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
+    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
+    const size_t sfc_idx = size_t(igpt)*ncl + icol;
+
+    const F pi = F(3.14159265358979323846);
+    const F eps = Lim<F>::eps();
+    const F tau_thres = sqrt(sqrt(eps));
+
+    const Vec<F,V> D = load_cols<F,V>(secants + sfc_idx + size_t(imu)*ncl*ngpt, nld);
+    const F w = weights[imu];
+
+    const int t0 = ll*K;
+
+    F tr[K][V], sdn[K][V], sup[K][V];
+    Vec<F,V> lv[K];
+
+    // level sources at this lane's K levels (sweep order: level t is ABOVE layer t)
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int t = min(t0 + j, nlay);
+        const int ml = top_at_1 ? t : nlay - t;
+        lv[j] = load_cols<F,V>(lev_source + lev_base + size_t(ml)*ncl, nld);
+    }
+
+    F A[V], Bdn[V], Bup[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v) { A[v] = F(1.); Bdn[v] = F(0.); Bup[v] = F(0.); }
+
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int s = t0 + j;
+        const bool valid = s < nlay;
+        const int sc = min(s, nlay-1);
+        const int ml = top_at_1 ? sc : nlay-1-sc;
+        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl, nld);
+        const Vec<F,V> ls = load_cols<F,V>(lay_source + lay_base + size_t(ml)*ncl, nld);
+
+        #pragma unroll
+        for (int v=0; v<V; ++v)
+        {
+            // level source below this layer: next register, or the first level of the next level-lane
+            F lev_below;
+            if (j < K-1) lev_below = lv[j+1].v[v];
+            else         lev_below = shfl(lv[0].v[v], lane + CL);
+            const F lev_above = lv[j].v[v];
+
+            const F tau_loc = tv.v[v] * D.v[v];
+            const F trans = exp(-tau_loc);
+            const F fact = tau_loc > tau_thres ?
+                (F(1.) - trans) / tau_loc - trans :
+                tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
+            const F omt = F(1.) - trans;
+            const F s_dn = omt * lev_below + F(2.) * fact * (ls.v[v] - lev_below);
+            const F s_up = omt * lev_above + F(2.) * fact * (ls.v[v] - lev_above);
+
+            tr[j][v]  = valid ? trans : F(1.);
+            sdn[j][v] = valid ? s_dn : F(0.);
+            sup[j][v] = valid ? s_up : F(0.);
+
+            Bdn[v] = tr[j][v] * Bdn[v] + sdn[j][v];
+            Bup[v] += A[v] * sup[j][v];
+            A[v] *= tr[j][v];
+        }
+    }
+
+    const Vec<F,V> emis = load_cols<F,V>(sfc_emis + sfc_idx, nld);
+    const Vec<F,V> ssrc = load_cols<F,V>(sfc_src + sfc_idx, nld);
+    Vec<F,V> inc;
+    if (inc_flux != nullptr) inc = load_cols<F,V>(inc_flux + sfc_idx, nld);
+    Vec<F,V> sjac;
+    if constexpr (JAC) sjac = load_cols<F,V>(sfc_src_jac + sfc_idx, nld);
+
+    F dn_in[V], up_in[V], jac_in[V];
+
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        // ---- downward: inclusive scan over level-lanes 0..ll
+        F a = A[v], b = Bdn[v];
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(a, lane - d*CL);
+            const F b2 = shfl(b, lane - d*CL);
+            if (ll >= d) { b = a*b2 + b; a = a*a2; }
+        }
+        F ae = shfl(a, lane - CL), be = shfl(b, lane - CL);     // exclusive
+        if (ll == 0) { ae = F(1.); be = F(0.); }
+        const F dn_top = (inc_flux != nullptr) ? inc.v[v] / pi : F(0.);
+        dn_in[v] = ae*dn_top + be;
+        const F dn_sfc = shfl(a*dn_top + b, (LL-1)*CL + cl);
+
+        // ---- surface
+        const F up_sfc = dn_sfc * (F(1.) - emis.v[v]) + emis.v[v] * ssrc.v[v];
+
+        // ---- upward: inclusive suffix scan over level-lanes ll..7
+        a = A[v]; b = Bup[v];
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(a, lane + d*CL);
+            const F b2 = shfl(b, lane + d*CL);
+            if (ll + d < LL) { b = a*b2 + b; a = a*a2; }
+        }
+        ae = shfl(a, lane + CL); be = shfl(b, lane + CL);
+        if (ll == LL-1) { ae = F(1.); be = F(0.); }
+        up_in[v] = ae*up_sfc + be;
+        if constexpr (JAC) jac_in[v] = ae * emis.v[v] * sjac.v[v];
+    }
+
+    // ---- replay this lane's K layers and store its K levels
+    const F scale = pi * w;
+    Vec<F,V> oup[K], odn[K], ojac[K];
+
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        F dn = dn_in[v];
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            odn[j].v[v] = scale * dn;
+            dn = tr[j][v]*dn + sdn[j][v];
+        }
+        F up = up_in[v];
+        F jc = JAC ? jac_in[v] : F(0.);
+        #pragma unroll
+        for (int j=K-1; j>=0; --j)
+        {
+            up = tr[j][v]*up + sup[j][v];
+            oup[j].v[v] = scale * up;
+            if constexpr (JAC) { jc = tr[j][v]*jc; ojac[j].v[v] = scale * jc; }
+        }
+    }
+
+    if (!active) return;
+
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int t = t0 + j;
+        if (t <= nlay)
+        {
+            const int ml = top_at_1 ? t : nlay - t;
+            const size_t o = lev_base + size_t(ml)*ncl;
+            if constexpr (ACC)
+            {
+                const Vec<F,V> pu = load_cols<F,V>(flux_up + o, nvalid);
+                const Vec<F,V> pd = load_cols<F,V>(flux_dn + o, nvalid);
+                #pragma unroll
+                for (int v=0; v<V; ++v) { oup[j].v[v] += pu.v[v]; odn[j].v[v] += pd.v[v]; }
+                if constexpr (JAC)
+                {
+                    const Vec<F,V> pj = load_cols<F,V>(flux_up_jac + o, nvalid);
+                    #pragma unroll
+                    for (int v=0; v<V; ++v) ojac[j].v[v] += pj.v[v];
+                }
+            }
+            store_cols<F,V>(flux_up + o, oup[j], nvalid);
+            store_cols<F,V>(flux_dn + o, odn[j], nvalid);
+            if constexpr (JAC) store_cols<F,V>(flux_up_jac + o, ojac[j], nvalid);
+        }
+    }
+}
+
+
+// Any-nlay fallback: one thread per (col, gpt), layer quantities recomputed in the second sweep
+// (no scratch). Used when nlay+1 > 8*K_MAX, and as the A/B baseline in bench.py --variant serial.
+template<typename F, bool JAC, bool ACC>
+__global__ void __launch_bounds__(256)
+lw_noscat_serial_kernel(
+        const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
+        const F* __restrict__ secants, const F* __restrict__ weights,
+        const F* __restrict__ tau, const F* __restrict__ lay_source, const F* __restrict__ lev_source,
+        const F* __restrict__ sfc_emis, const F* __restrict__ sfc_src, const F* __restrict__ inc_flux,
+        F* __restrict__ flux_up, F* __restrict__ flux_dn,
+        const F* __restrict__ sfc_src_jac, F* __restrict__ flux_up_jac)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int igpt = blockIdx.y;
+    if (icol >= ncol) return;
+
+    const int nlev = nlay+1;
+    const size_t ncl = size_t(ncol);
+    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
+    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
+    const size_t sfc_idx = size_t(igpt)*ncl + icol;
+    const F pi = F(3.14159265358979323846);
+    const F tau_thres = sqrt(sqrt(Lim<F>::eps()));
+    const F D = secants[sfc_idx + size_t(imu)*ncl*ngpt];
+    const F scale = pi * weights[imu];
+
+    auto layer = [&](const int s, F& trans, F& s_dn, F& s_up)
+    {
+        const int ml = top_at_1 ? s : nlay-1-s;
+        const int m_above = top_at_1 ? ml : ml+1;
+        const int m_below = top_at_1 ? ml+1 : ml;
+        const F tau_loc = tau[lay_base + size_t(ml)*ncl] * D;
+        const F ls = lay_source[lay_base + size_t(ml)*ncl];
+        const F lev_above = lev_source[lev_base + size_t(m_above)*ncl];
+        const F lev_below = lev_source[lev_base + size_t(m_below)*ncl];
+        trans = exp(-tau_loc);
+        const F fact = tau_loc > tau_thres ?
+            (F(1.) - trans) / tau_loc - trans :
+            tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
+        s_dn = (F(1.) - trans) * lev_below + F(2.) * fact * (ls - lev_below);
+        s_up = (F(1.) - trans) * lev_above + F(2.) * fact * (ls - lev_above);
+    };
+    auto put = [&](F* arr, const int t, const F val)
+    {
+        const int ml = top_at_1 ? t : nlay - t;
+        const size_t o = lev_base + size_t(ml)*ncl;
+        arr[o] = ACC ? arr[o] + scale*val : scale*val;
+    };
+
+    F dn = (inc_flux != nullptr) ? inc_flux[sfc_idx] / pi : F(0.);
+    for (int s=0; s<nlay; ++s)
+    {
+        F trans, s_dn, s_up;
+        layer(s, trans, s_dn, s_up);
+        put(flux_dn, s, dn);
+        dn = trans*dn + s_dn;
+    }
+    put(flux_dn, nlay, dn);
+
+    const F emis = sfc_emis[sfc_idx];
+    F up = dn * (F(1.) - emis) + emis * sfc_src[sfc_idx];
+    F jc = JAC ? emis * sfc_src_jac[sfc_idx] : F(0.);
+    put(flux_up, nlay, up);
+    if constexpr (JAC) put(flux_up_jac, nlay, jc);
+    for (int s=nlay-1; s>=0; --s)
+    {
+        F trans, s_dn, s_up;
+        layer(s, trans, s_dn, s_up);
+        up = trans*up + s_up;
+        put(flux_up, s, up);
+        if constexpr (JAC) { jc = trans*jc; put(flux_up_jac, s, jc); }
+    }
+}
+
+
+template<typename F>
+__global__ void lw_secants_array_kernel(
+        const int ncol, const int ngpt, const int n_gauss_quad, const int max_gauss_pts,
+        const F* __restrict__ gauss_Ds, F* __restrict__ secants)
+{
+    const size_t n = size_t(ncol)*ngpt*n_gauss_quad;
+    for (size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x)*blockDim.x)
+    {
+        const int imu = int(i / (size_t(ncol)*ngpt));
+        secants[i] = gauss_Ds[imu + (n_gauss_quad-1)*max_gauss_pts];
+    }
+}
+
+
+// level array (ncol,nlay+1) += / = sum over g-points of a (ncol,nlay+1,ngpt) array; used for do_broadband
+template<typename F>
+__global__ void sum_gpt_kernel(const size_t ncl_lev, const int ngpt, const F* __restrict__ in, F* __restrict__ out)
+{
+    const size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (i >= ncl_lev) return;
+    F s = F(0.);
+    for (int ig=0; ig<ngpt; ++ig) s += in[i + size_t(ig)*ncl_lev];
+    out[i] = s;
+}
+
+
+template<typename F, int V, int K>
+void launch_scan_k(
+        hipStream_t st, const dim3 grid, const bool jac, const bool acc,
+        const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn,
+        const F* sfc_src_jac, F* flux_up_jac)
+{
+#define RRX_LW_ARGS ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
+        sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, sfc_src_jac, flux_up_jac
+    if (jac)
+    {
+        if (acc) lw_noscat_scan_kernel<F,V,K,true,true><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+        else     lw_noscat_scan_kernel<F,V,K,true,false><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+    }
+    else
+    {
+        if (acc) lw_noscat_scan_kernel<F,V,K,false,true><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+        else     lw_noscat_scan_kernel<F,V,K,false,false><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+    }
+}
+
+template<typename F, int V>
+bool launch_scan(
+        hipStream_t st, const bool jac, const bool acc,
+        const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn,
+        const F* sfc_src_jac, F* flux_up_jac)
+{
+    const dim3 grid(ceil_div(ncol, 4*CL*V), ngpt);
+    const int need = ceil_div(nlay+1, LL);
+#define RRX_LW_K(KK) if (need <= KK) { launch_scan_k<F,V,KK>(st, grid, jac, acc, RRX_LW_ARGS); return true; }
+    RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) RRX_LW_K(24) RRX_LW_K(33)
+#undef RRX_LW_K
+    return false;
+}
+
+int g_lw_variant = 0;   // 0 = auto (scan), 1 = force serial, 2 = scan with V=1
+
+#define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
+        sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac
+
+template<typename F>
+int lw_solver_noscat_impl(
+        const int ncol, const int nlay, const int ngpt, const Bool top_at_1, const int nmus,
+        const F* secants, const F* weights,
+        const F* tau, const F* lay_source, const F* lev_source,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux,
+        F* flux_up, F* flux_dn,
+        const Bool do_broadband, F* flux_up_loc, F* flux_dn_loc,
+        const Bool do_jacobians, const F* sfc_src_jac, F* flux_up_jac,
+        void* stream)
+{
+    RRX_TRY
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+    if (nmus < 1 || nmus > 4) throw std::runtime_error("n_quad_angs must be 1..4");
+    const bool jac = do_jacobians && sfc_src_jac != nullptr && flux_up_jac != nullptr;
+
+    // broadband mode: per-g-point fluxes go to a workspace, then are summed over g-points
+    F* up = flux_up; F* dn = flux_dn;
+    F* ws = nullptr;
+    const size_t nlevcol = size_t(ncol)*(nlay+1);
+    if (do_broadband)
+    {
+        if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
+        if (hipMallocAsync(reinterpret_cast<void**>(&ws), 2*nlevcol*ngpt*sizeof(F), st) != hipSuccess)
+            throw std::runtime_error("workspace allocation failed");
+        up = ws; dn = ws + nlevcol*ngpt;
+    }
+
+    constexpr int VMAX = (sizeof(F) == 8) ? 2 : 4;
+    for (int imu=0; imu<nmus; ++imu)
+    {
+        const bool acc = imu > 0;
+        bool done = false;
+        if (g_lw_variant != 1)
+        {
+            if (g_lw_variant != 2 && ncol % VMAX == 0)
+                done = launch_scan<F,VMAX>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else
+                done = launch_scan<F,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+        }
+        if (!done)
+        {
+            const dim3 grid(ceil_div(ncol, 256), ngpt);
+#define RRX_LW_SERIAL(J, A) lw_noscat_serial_kernel<F,J,A><<<grid, 256, 0, st>>>( \
+        ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
+        sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac)
+            if (jac) { if (acc) RRX_LW_SERIAL(true, true); else RRX_LW_SERIAL(true, false); }
+            else     { if (acc) RRX_LW_SERIAL(false, true); else RRX_LW_SERIAL(false, false); }
+#undef RRX_LW_SERIAL
+        }
+    }
+
+    if (do_broadband)
+    {
+        const int nb = ceil_div(nlevcol, 256);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, up, flux_up_loc);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dn, flux_dn_loc);
+        (void)hipFreeAsync(ws, st);
+    }
+    RRX_CATCH("rrx_lw_solver_noscat")
+}
+}  // namespace
+
+
+extern "C"
+{
+int rrx_set_lw_variant(int v) { g_lw_variant = v; return 0; }
+
+int rrx_lw_secants_array_f64(int ncol, int ngpt, int n_gauss_quad, int max_gauss_pts, const double* gauss_Ds, double* secants, void* stream)
+{
+    RRX_TRY
+    lw_secants_array_kernel<double><<<rrx::ceil_div(size_t(ncol)*ngpt*n_gauss_quad, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            ncol, ngpt, n_gauss_quad, max_gauss_pts, gauss_Ds, secants);
+    RRX_CATCH("rrx_lw_secants_array")
+}
+
+int rrx_lw_secants_array_f32(int ncol, int ngpt, int n_gauss_quad, int max_gauss_pts, const float* gauss_Ds, float* secants, void* stream)
+{
+    RRX_TRY
+    lw_secants_array_kernel<float><<<rrx::ceil_div(size_t(ncol)*ngpt*n_gauss_quad, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            ncol, ngpt, n_gauss_quad, max_gauss_pts, gauss_Ds, secants);
+    RRX_CATCH("rrx_lw_secants_array")
+}
+
+int rrx_lw_solver_noscat_f64(
+        int ncol, int nlay, int ngpt, Bool top_at_1, int nmus,
+        const double* secants, const double* weights,
+        const double* tau, const double* lay_source, const double* lev_source,
+        const double* sfc_emis, const double* sfc_src, const double* inc_flux,
+        double* flux_up, double* flux_dn,
+        Bool do_broadband, double* flux_up_loc, double* flux_dn_loc,
+        Bool do_jacobians, const double* sfc_src_jac, double* flux_up_jac, void* stream)
+{
+    return lw_solver_noscat_impl<double>(ncol, nlay, ngpt, top_at_1, nmus, secants, weights, tau, lay_source, lev_source,
+            sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, do_broadband, flux_up_loc, flux_dn_loc,
+            do_jacobians, sfc_src_jac, flux_up_jac, stream);
+}
+
+int rrx_lw_solver_noscat_f32(
+        int ncol, int nlay, int ngpt, Bool top_at_1, int nmus,
+        const float* secants, const float* weights,
+        const float* tau, const float* lay_source, const float* lev_source,
+        const float* sfc_emis, const float* sfc_src, const float* inc_flux,
+        float* flux_up, float* flux_dn,
+        Bool do_broadband, float* flux_up_loc, float* flux_dn_loc,
+        Bool do_jacobians, const float* sfc_src_jac, float* flux_up_jac, void* stream)
+{
+    return lw_solver_noscat_impl<float>(ncol, nlay, ngpt, top_at_1, nmus, secants, weights, tau, lay_source, lev_source,
+            sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, do_broadband, flux_up_loc, flux_dn_loc,
+            do_jacobians, sfc_src_jac, flux_up_jac, stream);
+}
+}

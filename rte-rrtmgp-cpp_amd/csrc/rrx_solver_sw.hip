@@ -1,0 +1,488 @@
+// Shortwave two-stream solver, fused: boundary conditions + two-stream coefficients + direct-beam source +
+// adding (albedo/source upward, fluxes downward) in ONE kernel with no global scratch. Replaces
+//   Rte_solver_kernels_cuda::sw_solver_2stream  (/root/reference/src_kernels_cuda/rte_solver_kernels_launchers.cu:289-447)
+// and its kernels apply_BC_kernel (x3), sw_source_2stream_kernel + sw_2stream_function, sw_adding_kernel
+// (/root/reference/src_kernels_cuda/rte_solver_kernels.cu:196-286,351-387,543-655).
+//
+// MI355X design (DESIGN.md section "sw_solver_2stream"): same wave tiling as the LW solver -- 8 column-lanes x
+// 8 level-lanes, each level-lane holding K consecutive layers in registers, every input read once and every
+// output written once. The four vertical recurrences are propagated between level-lanes with 3-step __shfl scans:
+//   direct beam      dir' = t_noscat * dir                                  (product scan, downward)
+//   albedo           a'   = r + t^2 a / (1 - r a)   = Moebius map [[t^2-r^2, r], [-r, 1]]   (2x2 matrix scan, upward)
+//   diffuse source   s'   = alpha s + beta          (affine scan, upward;  alpha = t/(1 - r a))
+//   diffuse down     d'   = alpha d + b             (affine scan, downward)
+// Inside a lane the K layers are always replayed with the reference's own formulas.
+#include "rrx_common.h"
+#include "rrx_hip.h"
+
+namespace
+{
+using namespace rrx;
+
+constexpr int CL = 8;
+constexpr int LL = 8;
+
+template<typename F>
+struct TwoStream { F r_dif, t_dif, r_dir, t_dir, t_noscat; };
+
+// /root/reference/src_kernels_cuda/rte_solver_kernels.cu:543-592 (Zdunkowski PIFM two-stream, Ukkonen clamps)
+template<typename F>
+__device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, const F g, const F mu0)
+{
+    TwoStream<F> o;
+    const F tmin = Lim<F>::eps();
+    const F mu0_inv = F(1.)/mu0;
+    const F gamma1 = (F(8.) - ssa * (F(5.) + F(3.) * g)) * F(.25);
+    const F gamma2 = F(3.) * (ssa * (F(1.) - g)) * F(.25);
+    const F gamma3 = (F(2.) - F(3.) * mu0 * g) * F(.25);
+    const F gamma4 = F(1.) - gamma3;
+    const F alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+    const F alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+    const F k = sqrt(max((gamma1 - gamma2) * (gamma1 + gamma2), Lim<F>::k_min()));
+    const F exp_minusktau = exp(-tau * k);
+    const F exp_minus2ktau = exp_minusktau * exp_minusktau;
+    const F rt_term = F(1.) / (k * (F(1.) + exp_minus2ktau) + gamma1 * (F(1.) - exp_minus2ktau));
+    o.r_dif = rt_term * gamma2 * (F(1.) - exp_minus2ktau);
+    o.t_dif = rt_term * F(2.) * k * exp_minusktau;
+    o.t_noscat = exp(-tau * mu0_inv);
+    const F k_mu = k * mu0;
+    const F k_gamma3 = k * gamma3;
+    const F k_gamma4 = k * gamma4;
+    const F fact = (abs(F(1.) - k_mu*k_mu) > tmin) ? F(1.) - k_mu*k_mu : tmin;
+    const F rt_term2 = ssa * rt_term / fact;
+    F r_dir = rt_term2 * ((F(1.) - k_mu) * (alpha2 + k_gamma3) -
+                          (F(1.) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
+                          F(2.) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * o.t_noscat);
+    F t_dir = -rt_term2 * ((F(1.) + k_mu) * (alpha1 + k_gamma4) * o.t_noscat -
+                           (F(1.) - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * o.t_noscat -
+                           F(2.) * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+    o.r_dir = max(tmin, min(r_dir, F(1.) - o.t_noscat));
+    o.t_dir = max(tmin, min(t_dir, F(1.) - o.t_noscat - o.r_dir));
+    return o;
+}
+
+
+template<typename F, int V, int K>
+__global__ void __launch_bounds__(256)
+sw_2stream_scan_kernel(
+        const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
+        const F* __restrict__ sfc_alb_dir, const F* __restrict__ sfc_alb_dif,
+        const F* __restrict__ inc_flux_dir, const F* __restrict__ inc_flux_dif,
+        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cl = lane & (CL-1);
+    const int ll = lane >> 3;
+    const int igpt = blockIdx.y;
+    const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    if (wave_col0 >= ncol) return;
+
+    int icol = wave_col0 + cl*V;
+    int nvalid = ncol - icol;
+    const bool active = nvalid > 0;
+    if (!active) { icol = wave_col0; nvalid = 1; }
+    if (nvalid > V) nvalid = V;
+    const int nld = active ? nvalid : 1;
+
+    const int nlev = nlay + 1;
+    const size_t ncl = size_t(ncol);
+    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
+    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
+    const size_t sfc_idx = size_t(igpt)*ncl + icol;
+    const int t0 = ll*K;
+
+    const Vec<F,V> mu = load_cols<F,V>(mu0 + icol, nld);
+
+    // per-layer state (see header comment); names follow their LAST meaning
+    F rp[K][V];      // r_dif            -> p = r_dif*denom
+    F al[K][V];      // t_dif            -> alpha = t_dif*denom
+    F sb[K][V];      // source_up        -> beta -> src at level t0+j
+    F qb[K][V];      // source_dn        -> q = source_dn*denom -> b
+    F alb[K][V];     // albedo at level t0+j
+    F dirv[K][V];    // direct beam at level t0+j
+
+    F Tloc[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v) Tloc[v] = F(1.);
+
+    // ---- (a) two-stream coefficients, (b) direct beam relative to the lane's incoming beam
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int s = t0 + j;
+        const bool valid = s < nlay;
+        const int sc = min(s, nlay-1);
+        const int ml = top_at_1 ? sc : nlay-1-sc;
+        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl, nld);
+        const Vec<F,V> wv = load_cols<F,V>(ssa + lay_base + size_t(ml)*ncl, nld);
+        const Vec<F,V> gv = load_cols<F,V>(g   + lay_base + size_t(ml)*ncl, nld);
+        #pragma unroll
+        for (int v=0; v<V; ++v)
+        {
+            const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v]);
+            dirv[j][v] = Tloc[v];
+            rp[j][v] = valid ? ts.r_dif : F(0.);
+            al[j][v] = valid ? ts.t_dif : F(1.);
+            sb[j][v] = valid ? ts.r_dir * Tloc[v] : F(0.);
+            qb[j][v] = valid ? ts.t_dir * Tloc[v] : F(0.);
+            Tloc[v] *= valid ? ts.t_noscat : F(1.);
+        }
+    }
+
+    const Vec<F,V> inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx, nld);
+    const Vec<F,V> a_dir = load_cols<F,V>(sfc_alb_dir + sfc_idx, nld);
+    const Vec<F,V> a_dif = load_cols<F,V>(sfc_alb_dif + sfc_idx, nld);
+    Vec<F,V> inc_dif;
+    if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx, nld);
+
+    Vec<F,V> oup[K], odn[K];
+
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        // ---- direct beam: inclusive product scan over level-lanes 0..ll
+        F pr = Tloc[v];
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F p2 = shfl(pr, lane - d*CL);
+            if (ll >= d) pr *= p2;
+        }
+        F pe = shfl(pr, lane - CL);
+        if (ll == 0) pe = F(1.);
+        const F dir_top = inc_dir.v[v] * mu.v[v];
+        const F dir_in = dir_top * pe;
+        const F dir_sfc = shfl(dir_top * pr, (LL-1)*CL + cl);
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            dirv[j][v] *= dir_in;
+            sb[j][v] *= dir_in;
+            qb[j][v] *= dir_in;
+        }
+
+        // ---- albedo: Moebius composite of this lane's layers (layer K-1 applied first), normalised to m11 = 1
+        F m00 = F(1.), m01 = F(0.), m10 = F(0.), m11 = F(1.);
+        #pragma unroll
+        for (int j=K-1; j>=0; --j)
+        {
+            const F r = rp[j][v], t = al[j][v];
+            const F e = t*t - r*r;
+            const F n00 = e*m00 + r*m10, n01 = e*m01 + r*m11;
+            const F n10 = m10 - r*m00,   n11 = m11 - r*m01;
+            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+        }
+        {
+            const F inv = F(1.)/m11;
+            m00 *= inv; m01 *= inv; m10 *= inv; m11 = F(1.);
+        }
+        // inclusive suffix scan: S(ll) = M_ll * M_{ll+1} * ... * M_7
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F p00 = shfl(m00, lane + d*CL), p01 = shfl(m01, lane + d*CL);
+            const F p10 = shfl(m10, lane + d*CL);            // partner m11 == 1
+            if (ll + d < LL)
+            {
+                const F n00 = m00*p00 + m01*p10, n01 = m00*p01 + m01;
+                const F n10 = m10*p00 + p10,     n11 = m10*p01 + F(1.);
+                const F inv = F(1.)/n11;
+                m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
+            }
+        }
+        F e00 = shfl(m00, lane + CL), e01 = shfl(m01, lane + CL), e10 = shfl(m10, lane + CL);
+        if (ll == LL-1) { e00 = F(1.); e01 = F(0.); e10 = F(0.); }
+        const F alb_sfc = a_dif.v[v];
+        F a = (e00*alb_sfc + e01) / (e10*alb_sfc + F(1.));      // albedo at the bottom of this lane's chunk
+
+        // ---- replay albedo upward; build alpha, beta, p, q and the lane's affine composites
+        F As = F(1.), Bs = F(0.), Bd = F(0.);    // As: product of alpha (shared); Bs: source (upward); Bd: down
+        #pragma unroll
+        for (int j=K-1; j>=0; --j)
+        {
+            const F r = rp[j][v], t = al[j][v];
+            const F denom = F(1.)/(F(1.) - r*a);
+            const F alpha = t*denom;
+            const F beta = sb[j][v] + alpha*a*qb[j][v];
+            a = r + t*alpha*a;
+            alb[j][v] = a;
+            al[j][v] = alpha;
+            sb[j][v] = beta;
+            rp[j][v] = r*denom;
+            qb[j][v] = qb[j][v]*denom;
+            Bs = alpha*Bs + beta;
+            As *= alpha;
+        }
+
+        // ---- source: suffix affine scan (lanes below applied first)
+        F sa = As, sbb = Bs;
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(sa, lane + d*CL), b2 = shfl(sbb, lane + d*CL);
+            if (ll + d < LL) { sbb = sa*b2 + sbb; sa = sa*a2; }
+        }
+        F ae = shfl(sa, lane + CL), be = shfl(sbb, lane + CL);
+        if (ll == LL-1) { ae = F(1.); be = F(0.); }
+        const F src_sfc = dir_sfc * a_dir.v[v];
+        F s = ae*src_sfc + be;                                   // src at the bottom of this lane's chunk
+
+        // replay src upward; b_j = p_j*src_below + q_j; accumulate the downward composite
+        F Q = F(1.);
+        #pragma unroll
+        for (int j=K-1; j>=0; --j)
+        {
+            const F b = rp[j][v]*s + qb[j][v];
+            s = al[j][v]*s + sb[j][v];
+            sb[j][v] = s;
+            qb[j][v] = b;
+            Bd += Q*b;
+            Q *= al[j][v];
+        }
+
+        // ---- diffuse down: prefix affine scan
+        F da = As, db = Bd;
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(da, lane - d*CL), b2 = shfl(db, lane - d*CL);
+            if (ll >= d) { db = da*b2 + db; da = da*a2; }
+        }
+        ae = shfl(da, lane - CL); be = shfl(db, lane - CL);
+        if (ll == 0) { ae = F(1.); be = F(0.); }
+        const F dn_top = (inc_flux_dif != nullptr) ? inc_dif.v[v] : F(0.);
+        F dn = ae*dn_top + be;
+
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            oup[j].v[v] = dn*alb[j][v] + sb[j][v];
+            odn[j].v[v] = dn + dirv[j][v];
+            dn = al[j][v]*dn + qb[j][v];
+        }
+    }
+
+    if (!active) return;
+
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int t = t0 + j;
+        if (t <= nlay)
+        {
+            const int ml = top_at_1 ? t : nlay - t;
+            const size_t o = lev_base + size_t(ml)*ncl;
+            Vec<F,V> od;
+            #pragma unroll
+            for (int v=0; v<V; ++v) od.v[v] = dirv[j][v];
+            store_cols<F,V>(flux_up + o, oup[j], nvalid);
+            store_cols<F,V>(flux_dn + o, odn[j], nvalid);
+            store_cols<F,V>(flux_dir + o, od, nvalid);
+        }
+    }
+}
+
+
+// Any-nlay fallback: one thread per (col, gpt); r_dif, t_dif, source_up/dn, albedo, src, denom kept in a
+// caller-provided global workspace laid out like the reference's temporaries.
+template<typename F>
+__global__ void __launch_bounds__(256)
+sw_2stream_serial_kernel(
+        const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
+        const F* __restrict__ sfc_alb_dir, const F* __restrict__ sfc_alb_dif,
+        const F* __restrict__ inc_flux_dir, const F* __restrict__ inc_flux_dif,
+        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir,
+        F* __restrict__ ws)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int igpt = blockIdx.y;
+    if (icol >= ncol) return;
+
+    const int nlev = nlay+1;
+    const size_t ncl = size_t(ncol);
+    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
+    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
+    const size_t sfc_idx = size_t(igpt)*ncl + icol;
+    const size_t opt = ncl*nlay*ngpt;
+    F* w_r = ws; F* w_t = ws + opt; F* w_su = ws + 2*opt; F* w_sd = ws + 3*opt; F* w_den = ws + 4*opt;
+    F* w_alb = ws + 5*opt; F* w_src = w_alb + ncl*nlev*ngpt;
+
+    auto mlev = [&](const int t) { return lev_base + size_t(top_at_1 ? t : nlay - t)*ncl; };
+    auto mlay = [&](const int s) { return lay_base + size_t(top_at_1 ? s : nlay-1-s)*ncl; };
+
+    const F mu = mu0[icol];
+    F dir = inc_flux_dir[sfc_idx] * mu;
+    for (int s=0; s<nlay; ++s)
+    {
+        const size_t il = mlay(s);
+        const TwoStream<F> ts = two_stream<F>(tau[il], ssa[il], g[il], mu);
+        w_r[il] = ts.r_dif; w_t[il] = ts.t_dif;
+        w_su[il] = ts.r_dir * dir; w_sd[il] = ts.t_dir * dir;
+        flux_dir[mlev(s)] = dir;
+        dir *= ts.t_noscat;
+    }
+    flux_dir[mlev(nlay)] = dir;
+
+    F a = sfc_alb_dif[sfc_idx];
+    F sr = dir * sfc_alb_dir[sfc_idx];
+    w_alb[mlev(nlay)] = a; w_src[mlev(nlay)] = sr;
+    for (int s=nlay-1; s>=0; --s)
+    {
+        const size_t il = mlay(s);
+        const F r = w_r[il], t = w_t[il];
+        const F denom = F(1.)/(F(1.) - r*a);
+        w_den[il] = denom;
+        sr = w_su[il] + t*denom*(sr + a*w_sd[il]);
+        a = r + t*t*a*denom;
+        w_alb[mlev(s)] = a; w_src[mlev(s)] = sr;
+    }
+
+    F dn = (inc_flux_dif != nullptr) ? inc_flux_dif[sfc_idx] : F(0.);
+    flux_up[mlev(0)] = dn*a + sr;
+    flux_dn[mlev(0)] = dn + flux_dir[mlev(0)];
+    for (int s=0; s<nlay; ++s)
+    {
+        const size_t il = mlay(s);
+        const size_t lv = mlev(s+1);
+        dn = (w_t[il]*dn + w_r[il]*w_src[lv] + w_sd[il]) * w_den[il];
+        flux_up[lv] = dn*w_alb[lv] + w_src[lv];
+        flux_dn[lv] = dn + flux_dir[lv];
+    }
+}
+
+
+template<typename F>
+__global__ void sum_gpt_kernel(const size_t ncl_lev, const int ngpt, const F* __restrict__ in, F* __restrict__ out)
+{
+    const size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (i >= ncl_lev) return;
+    F s = F(0.);
+    for (int ig=0; ig<ngpt; ++ig) s += in[i + size_t(ig)*ncl_lev];
+    out[i] = s;
+}
+
+template<typename F>
+__global__ void apply_BC_kernel(const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* __restrict__ inc_flux, const F* __restrict__ factor, F* __restrict__ flux_dn)
+{
+    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
+    const int igpt = blockIdx.y;
+    if (icol >= ncol) return;
+    const size_t o = size_t(icol) + size_t(top_at_1 ? 0 : nlay)*ncol + size_t(igpt)*ncol*(nlay+1);
+    F v = F(0.);
+    if (inc_flux != nullptr) v = inc_flux[icol + size_t(igpt)*ncol];
+    if (factor != nullptr) v *= factor[icol];
+    flux_dn[o] = v;
+}
+
+int g_sw_variant = 0;   // 0 = auto (scan), 1 = force serial
+
+template<typename F, int V>
+bool launch_scan(hipStream_t st,
+        const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
+        const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
+{
+    const dim3 grid(ceil_div(ncol, 4*CL*V), ngpt);
+    const int need = ceil_div(nlay+1, LL);
+#define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK><<<grid, 256, 0, st>>>( \
+        ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+        flux_up, flux_dn, flux_dir); return true; }
+    RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33)
+#undef RRX_SW_K
+    return false;
+}
+
+template<typename F>
+int sw_solver_2stream_impl(
+        const int ncol, const int nlay, const int ngpt, const Bool top_at_1,
+        const F* tau, const F* ssa, const F* g, const F* mu0,
+        const F* sfc_alb_dir, const F* sfc_alb_dif, const F* inc_flux_dir,
+        F* flux_up, F* flux_dn, F* flux_dir,
+        const Bool has_dif_bc, const F* inc_flux_dif,
+        const Bool do_broadband, F* flux_up_loc, F* flux_dn_loc, F* flux_dir_loc, void* stream)
+{
+    RRX_TRY
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+    const F* dif = has_dif_bc ? inc_flux_dif : nullptr;
+
+    F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
+    F* ws = nullptr;
+    const size_t nlevcol = size_t(ncol)*(nlay+1);
+    if (do_broadband)
+    {
+        if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
+            throw std::runtime_error("do_broadband needs flux_*_loc");
+        if (hipMallocAsync(reinterpret_cast<void**>(&ws), 3*nlevcol*ngpt*sizeof(F), st) != hipSuccess)
+            throw std::runtime_error("workspace allocation failed");
+        up = ws; dn = ws + nlevcol*ngpt; dr = ws + 2*nlevcol*ngpt;
+    }
+
+    bool done = false;
+    if (g_sw_variant != 1)
+        done = launch_scan<F,1>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                inc_flux_dir, dif, up, dn, dr);
+    if (!done)
+    {
+        F* ws2 = nullptr;
+        const size_t words = 5*size_t(ncol)*nlay*ngpt + 2*nlevcol*ngpt;
+        if (hipMallocAsync(reinterpret_cast<void**>(&ws2), words*sizeof(F), st) != hipSuccess)
+            throw std::runtime_error("workspace allocation failed");
+        const dim3 grid(ceil_div(ncol, 256), ngpt);
+        sw_2stream_serial_kernel<F><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0,
+                sfc_alb_dir, sfc_alb_dif, inc_flux_dir, dif, up, dn, dr, ws2);
+        (void)hipFreeAsync(ws2, st);
+    }
+
+    if (do_broadband)
+    {
+        const int nb = ceil_div(nlevcol, 256);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, up, flux_up_loc);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dn, flux_dn_loc);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dr, flux_dir_loc);
+        (void)hipFreeAsync(ws, st);
+    }
+    RRX_CATCH("rrx_sw_solver_2stream")
+}
+
+template<typename F>
+int apply_BC_impl(int ncol, int nlay, int ngpt, Bool top_at_1, const F* inc, const F* factor, F* flux, void* stream)
+{
+    RRX_TRY
+    apply_BC_kernel<F><<<dim3(ceil_div(ncol, 256), ngpt), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            ncol, nlay, ngpt, top_at_1, inc, factor, flux);
+    RRX_CATCH("rrx_apply_BC")
+}
+}  // namespace
+
+
+extern "C"
+{
+int rrx_set_sw_variant(int v) { g_sw_variant = v; return 0; }
+
+#define RRX_DEFINE_SW(F, SFX) \
+int rrx_sw_solver_2stream##SFX( \
+        int ncol, int nlay, int ngpt, RrxBool top_at_1, \
+        const F* tau, const F* ssa, const F* g, const F* mu0, \
+        const F* sfc_alb_dir, const F* sfc_alb_dif, const F* inc_flux_dir, \
+        F* flux_up, F* flux_dn, F* flux_dir, \
+        RrxBool has_dif_bc, const F* inc_flux_dif, \
+        RrxBool do_broadband, F* flux_up_loc, F* flux_dn_loc, F* flux_dir_loc, void* stream) \
+{ \
+    return sw_solver_2stream_impl<F>(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, \
+            flux_up, flux_dn, flux_dir, has_dif_bc, inc_flux_dif, do_broadband, flux_up_loc, flux_dn_loc, flux_dir_loc, stream); \
+} \
+int rrx_apply_BC_factor##SFX(int ncol, int nlay, int ngpt, RrxBool top_at_1, const F* inc_flux_dir, const F* mu0, F* gpt_flux_dir, void* stream) \
+{ return apply_BC_impl<F>(ncol, nlay, ngpt, top_at_1, inc_flux_dir, mu0, gpt_flux_dir, stream); } \
+int rrx_apply_BC_0##SFX(int ncol, int nlay, int ngpt, RrxBool top_at_1, F* gpt_flux_dn, void* stream) \
+{ return apply_BC_impl<F>(ncol, nlay, ngpt, top_at_1, (const F*)nullptr, (const F*)nullptr, gpt_flux_dn, stream); } \
+int rrx_apply_BC_gpt##SFX(int ncol, int nlay, int ngpt, RrxBool top_at_1, const F* inc_flux_dif, F* gpt_flux_dn, void* stream) \
+{ return apply_BC_impl<F>(ncol, nlay, ngpt, top_at_1, inc_flux_dif, (const F*)nullptr, gpt_flux_dn, stream); }
+
+RRX_DEFINE_SW(double, _f64)
+RRX_DEFINE_SW(float, _f32)
+}

@@ -1,0 +1,128 @@
+"""Launcher-level orchestration of one LW / SW solve, generic over a backend object.
+
+Mirrors, call for call, what the reference's host classes do around the kernel launchers:
+  Radiation_solver_longwave::solve_gpu   /root/reference/src_test/Radiation_solver.cu:419-680
+  Radiation_solver_shortwave::solve_gpu  /root/reference/src_test/Radiation_solver.cu:683-950
+  Gas_optics_rrtmgp_gpu::gas_optics / compute_gas_taus / source   /root/reference/src_cuda/Gas_optics_rrtmgp.cu:907-1201
+  Rte_lw_gpu::rte_lw                     /root/reference/src_cuda/Rte_lw.cu:60-136
+  Rte_sw_gpu::rte_sw                     /root/reference/src_cuda/Rte_sw.cu:116-161
+  Fluxes_broadband_gpu::reduce           /root/reference/src_cuda/Fluxes.cu:39-54
+
+The backend is either HipKernels (product path, torch CUDA tensors) or, in tests only, a CPU checker from
+oracle/oracle_py.py (numpy). This module never imports the oracle.
+"""
+import numpy as np
+
+# Gauss-Jacobi-5 quadrature, R. J. Hogan 2023 (values as in /root/reference/src/Rte_lw.cpp:140-152); (n_angles, point)
+MAX_GAUSS_PTS = 4
+GAUSS_DS = np.array([
+    [1./0.6096748751, 0., 0., 0.],
+    [1./0.2509907356, 1/0.7908473988, 0., 0.],
+    [1./0.1024922169, 1/0.4417960320, 1./0.8633751621, 0.],
+    [1./0.0454586727, 1/0.2322334416, 1./0.5740198775, 1./0.903077597]])
+GAUSS_WTS = np.array([
+    [1., 0., 0., 0.],
+    [0.2300253764, 0.7699746236, 0., 0.],
+    [0.0437820218, 0.3875796738, 0.5686383044, 0.],
+    [0.0092068785, 0.1285704278, 0.4323381850, 0.4298845087]])
+
+
+def upload_atmosphere(be, atm):
+    from .synthetic import Atmosphere
+    out = {}
+    for k, v in atm.__dict__.items():
+        if isinstance(v, np.ndarray):
+            out[k] = be.asarray(v)
+        elif isinstance(v, dict):
+            out[k] = {n: be.asarray(a) for n, a in v.items()}
+        else:
+            out[k] = v
+    return Atmosphere(**out)
+
+
+def _sfc_lay(atm):
+    # /root/reference/src_cuda/Gas_optics_rrtmgp.cu:1190 : play(1,1) > play(1,nlay) ? 1 : nlay
+    return atm.nlay if atm.top_at_1 else 1
+
+
+def gas_state(be, kd, atm, col_dry=None):
+    """col_dry, col_gas and the interpolation state shared by the optical-depth and source kernels."""
+    if col_dry is None:
+        col_dry = be.get_col_dry(atm.vmr["h2o"], atm.p_lev)
+    col_gas = be.fill_gases(kd, atm.vmr, col_dry)
+    it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+    return col_dry, col_gas, it
+
+
+def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False):
+    ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
+    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry)
+
+    tau = be.zeros((ngpt, nlay, ncol))
+    be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
+    src = be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm))
+
+    if cloud_lut is not None:
+        tau_cld = be.cloud_optics_1scl(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
+        be.inc_1scalar_by_1scalar_bybnd(tau, tau_cld, kd.band_lims_gpt)
+
+    sfc_emis_gpt = be.expand_and_transpose(kd.band_lims_gpt, atm.emis_sfc, ngpt)
+    gauss_Ds = be.asarray(GAUSS_DS)
+    weights = be.asarray(np.ascontiguousarray(GAUSS_WTS[n_gauss_angles-1, :n_gauss_angles]))
+    secants = be.lw_secants_array(ncol, ngpt, n_gauss_angles, MAX_GAUSS_PTS, gauss_Ds)
+
+    r = be.lw_solver_noscat(atm.top_at_1, secants, weights, tau, src["lay_src"], src["lev_src"],
+                            sfc_emis_gpt, src["sfc_src"], None, do_broadband=do_broadband)
+    if do_broadband:
+        flux_up, flux_dn = r["flux_up"], r["flux_dn"]
+    else:
+        flux_up = be.sum_broadband(r["flux_up"])
+        flux_dn = be.sum_broadband(r["flux_dn"])
+    flux_net = be.net_broadband_precalc(flux_dn, flux_up)
+    out = dict(flux_up=flux_up, flux_dn=flux_dn, flux_net=flux_net)
+    if keep:
+        out.update(tau=tau, lay_src=src["lay_src"], lev_src=src["lev_src"], sfc_src=src["sfc_src"],
+                   gpt_flux_up=r.get("flux_up"), gpt_flux_dn=r.get("flux_dn"), interp=it, col_gas=col_gas)
+    return out
+
+
+def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False):
+    ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
+    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry)
+
+    if fused_gas is None:
+        fused_gas = hasattr(be, "gas_optics_sw_fused")
+    if fused_gas:
+        tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol)); g = be.empty((ngpt, nlay, ncol))
+        be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
+    else:
+        tau_abs = be.zeros((ngpt, nlay, ncol))
+        be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau_abs)
+        tau_ray = be.compute_tau_rayleigh(kd, it, col_dry, col_gas)
+        tau, ssa, g = be.combine_abs_and_rayleigh(tau_abs, tau_ray)
+
+    toa_src = be.spread_col(ncol, kd.solar_source)
+    be.scaling_to_subset(toa_src, atm.tsi_scaling)
+
+    if cloud_lut is not None:
+        tc, wc, gc = be.cloud_optics_2str(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
+        if delta_cloud:
+            be.delta_scale_2str_k(tc, wc, gc)
+        be.inc_2stream_by_2stream_bybnd(tau, ssa, g, tc, wc, gc, kd.band_lims_gpt)
+
+    alb_dir = be.expand_and_transpose(kd.band_lims_gpt, atm.sfc_alb_dir, ngpt)
+    alb_dif = be.expand_and_transpose(kd.band_lims_gpt, atm.sfc_alb_dif, ngpt)
+
+    r = be.sw_solver_2stream(atm.top_at_1, tau, ssa, g, atm.mu0, alb_dir, alb_dif, toa_src, None, do_broadband=do_broadband)
+    if do_broadband:
+        flux_up, flux_dn, flux_dir = r["flux_up"], r["flux_dn"], r["flux_dir"]
+    else:
+        flux_up = be.sum_broadband(r["flux_up"])
+        flux_dn = be.sum_broadband(r["flux_dn"])
+        flux_dir = be.sum_broadband(r["flux_dir"])
+    flux_net = be.net_broadband_precalc(flux_dn, flux_up)
+    out = dict(flux_up=flux_up, flux_dn=flux_dn, flux_dn_dir=flux_dir, flux_net=flux_net)
+    if keep:
+        out.update(tau=tau, ssa=ssa, g=g, toa_src=toa_src, gpt_flux_up=r.get("flux_up"),
+                   gpt_flux_dn=r.get("flux_dn"), gpt_flux_dir=r.get("flux_dir"))
+    return out

@@ -1,0 +1,160 @@
+"""Shared parity machinery: replay a golden fixture (tests/golden/*.npz, produced by oracle/make_golden.py from the
+reference's own kernel text) through any backend and compare launcher by launcher."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+
+from rte_rrtmgp_cpp_amd import synthetic, pipeline
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MINI = dict(ngpt=32, nbnd=2, npres=10, nflav=3, nminor_lower=5, nminor_upper=3)
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def kdist_digest(kd):
+    h = hashlib.sha256()
+    for k in sorted(kd.__dict__):
+        v = kd.__dict__[k]
+        if isinstance(v, np.ndarray):
+            h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def rel_err(a, b):
+    """max |a-b| / (|b| + 1e-6*max|b|): relative error that does not blow up at the zeros of b."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.size == 0:
+        return 0.0
+    scale = np.abs(b) + 1e-6*np.max(np.abs(b)) + 1e-300
+    return float(np.max(np.abs(a - b) / scale))
+
+
+class Checker:
+    def __init__(self, be, tol):
+        self.be, self.tol, self.worst = be, tol, {}
+
+    def close(self, name, got, want, tol=None):
+        e = rel_err(self.be.to_numpy(got), want)
+        self.worst[name] = e
+        assert e <= (tol or self.tol), f"{name}: rel err {e:.3e} > {(tol or self.tol):.1e} ({self.be.name})"
+
+    def exact(self, name, got, want):
+        g = self.be.to_numpy(got)
+        assert np.array_equal(g.astype(np.int64), np.asarray(want).astype(np.int64)), f"{name}: integer mismatch ({self.be.name})"
+
+
+def dtype_of(G):
+    return G["lw_tau"].dtype
+
+
+def run_chain_case(be, G, tol):
+    """gas optics -> Planck -> LW solver -> broadband; gas optics + Rayleigh -> combine -> SW solver -> broadband."""
+    ck = Checker(be, tol)
+    ncol, nlay, top_at_1, _ = [int(x) for x in G["meta"]]
+    up = be.asarray
+    play, tlay, tlev, tsfc = up(G["p_lay"]), up(G["t_lay"]), up(G["t_lev"]), up(G["t_sfc"])
+    col_dry, col_gas = up(G["col_dry"]), up(G["col_gas"])
+
+    # the small kernels the reference keeps in its host classes: checked against the fixture's numpy inputs
+    if hasattr(be, "get_col_dry"):
+        ck.close("col_dry", be.get_col_dry(up(G["vmr_h2o"]), up(G["p_lev"])), G["col_dry"], tol=max(tol, 1e-12))
+
+    for kind in ("lw", "sw"):
+        kd0 = synthetic.make_kdist(kind, **MINI)
+        assert kdist_digest(kd0) == str(G[f"{kind}_kdist_digest"]), "synthetic k-distribution drifted: regenerate goldens"
+        kd = be.upload_kdist(kd0)
+        vmr = {n: up(G[f"vmr_{n}"]) for n in kd0.gas_names}
+        ck.close(f"{kind}_col_gas", be.fill_gases(kd, vmr, col_dry), G["col_gas"], tol=max(tol, 1e-12))
+        it = be.interpolation(kd, play, tlay, col_gas)
+        for k in ("jtemp", "jpress", "tropo", "jeta"):
+            ck.exact(f"{kind}_it_{k}", it[k], G[f"{kind}_it_{k}"])
+        for k in ("col_mix", "fminor", "fmajor"):
+            ck.close(f"{kind}_it_{k}", it[k], G[f"{kind}_it_{k}"])
+        # downstream kernels are fed the REFERENCE interpolation state so that errors do not compound
+        it = {k: up(G[f"{kind}_it_{k}"]) for k in it}
+        if kind == "lw":
+            tau = be.zeros((kd.ngpt, nlay, ncol))
+            be.compute_tau_absorption(kd, it, play, tlay, col_gas, tau)
+            ck.close("lw_tau", tau, G["lw_tau"])
+            src = be.compute_planck_source(kd, it, tlay, tlev, tsfc, nlay if top_at_1 else 1)
+            for k in ("lay_src", "lev_src", "sfc_src", "sfc_src_jac"):
+                ck.close("lw_" + k, src[k], G["lw_" + k])
+            sec = be.lw_secants_array(ncol, kd.ngpt, 1, 4, up(pipeline.GAUSS_DS))
+            ck.close("lw_secants", sec, G["lw_secants"])
+            fl = be.lw_solver_noscat(bool(top_at_1), up(G["lw_secants"]), up(np.array([1.0])), up(G["lw_tau"]),
+                                     up(G["lw_lay_src"]), up(G["lw_lev_src"]), up(G["lw_sfc_emis_gpt"]), up(G["lw_sfc_src"]))
+            ck.close("lw_gpt_flux_up", fl["flux_up"], G["lw_gpt_flux_up"])
+            ck.close("lw_gpt_flux_dn", fl["flux_dn"], G["lw_gpt_flux_dn"])
+            fu = be.sum_broadband(up(G["lw_gpt_flux_up"])); fd = be.sum_broadband(up(G["lw_gpt_flux_dn"]))
+            ck.close("lw_flux_up", fu, G["lw_flux_up"]); ck.close("lw_flux_dn", fd, G["lw_flux_dn"])
+            ck.close("lw_flux_net", be.net_broadband_precalc(up(G["lw_flux_dn"]), up(G["lw_flux_up"])), G["lw_flux_net"])
+            # broadband mode of the solver == sum of the per-g-point fluxes (CPU/Fortran semantics)
+            if be.name != "ref":
+                bb = be.lw_solver_noscat(bool(top_at_1), up(G["lw_secants"]), up(np.array([1.0])), up(G["lw_tau"]),
+                                         up(G["lw_lay_src"]), up(G["lw_lev_src"]), up(G["lw_sfc_emis_gpt"]), up(G["lw_sfc_src"]),
+                                         do_broadband=True)
+                ck.close("lw_bb_flux_up", bb["flux_up"], G["lw_flux_up"], tol=max(tol, 1e-12))
+                ck.close("lw_bb_flux_dn", bb["flux_dn"], G["lw_flux_dn"], tol=max(tol, 1e-12))
+        else:
+            tau_abs = be.zeros((kd.ngpt, nlay, ncol))
+            be.compute_tau_absorption(kd, it, play, tlay, col_gas, tau_abs)
+            ck.close("sw_tau_abs", tau_abs, G["sw_tau_abs"])
+            ck.close("sw_tau_ray", be.compute_tau_rayleigh(kd, it, col_dry, col_gas), G["sw_tau_ray"])
+            tau, ssa, g = be.combine_abs_and_rayleigh(up(G["sw_tau_abs"]), up(G["sw_tau_ray"]))
+            ck.close("sw_tau", tau, G["sw_tau"]); ck.close("sw_ssa", ssa, G["sw_ssa"]); ck.close("sw_g", g, G["sw_g"])
+            if hasattr(be, "gas_optics_sw_fused"):
+                t2 = be.empty(tau.shape); w2 = be.empty(tau.shape); g2 = be.empty(tau.shape)
+                be.gas_optics_sw_fused(kd, it, play, tlay, col_gas, col_dry, t2, w2, g2)
+                ck.close("sw_fused_tau", t2, G["sw_tau"]); ck.close("sw_fused_ssa", w2, G["sw_ssa"]); ck.close("sw_fused_g", g2, G["sw_g"])
+            fl = be.sw_solver_2stream(bool(top_at_1), up(G["sw_tau"]), up(G["sw_ssa"]), up(G["sw_g"]), up(G["mu0"]),
+                                      up(G["sw_alb_dir"]), up(G["sw_alb_dif"]), up(G["sw_toa_src"]))
+            ck.close("sw_gpt_flux_up", fl["flux_up"], G["sw_gpt_flux_up"])
+            ck.close("sw_gpt_flux_dn", fl["flux_dn"], G["sw_gpt_flux_dn"])
+            ck.close("sw_gpt_flux_dir", fl["flux_dir"], G["sw_gpt_flux_dir"])
+            ck.close("sw_flux_up", be.sum_broadband(up(G["sw_gpt_flux_up"])), G["sw_flux_up"])
+            if be.name != "ref":
+                bb = be.sw_solver_2stream(bool(top_at_1), up(G["sw_tau"]), up(G["sw_ssa"]), up(G["sw_g"]), up(G["mu0"]),
+                                          up(G["sw_alb_dir"]), up(G["sw_alb_dif"]), up(G["sw_toa_src"]), do_broadband=True)
+                ck.close("sw_bb_flux_up", bb["flux_up"], G["sw_flux_up"], tol=max(tol, 1e-12))
+                ck.close("sw_bb_flux_dn", bb["flux_dn"], G["sw_flux_dn"], tol=max(tol, 1e-12))
+                ck.close("sw_bb_flux_dir", bb["flux_dir"], G["sw_flux_dir"], tol=max(tol, 1e-12))
+    return ck.worst
+
+
+def run_random_case(be, G, tol):
+    ck = Checker(be, tol)
+    ncol, nlay, top_at_1, _ = [int(x) for x in G["meta"]]
+    up = be.asarray
+    ngpt = G["lw_tau"].shape[0]
+    sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS))
+    fl = be.lw_solver_noscat(bool(top_at_1), sec, up(np.array([1.0])), up(G["lw_tau"]), up(G["lw_lay_src"]), up(G["lw_lev_src"]),
+                             up(G["lw_emis"]), up(G["lw_sfc_src"]), do_jacobians=True, sfc_src_jac=up(G["lw_sfc_src_jac"]))
+    ck.close("lw_flux_up", fl["flux_up"], G["lw_flux_up"]); ck.close("lw_flux_dn", fl["flux_dn"], G["lw_flux_dn"])
+    ck.close("lw_flux_up_jac", fl["flux_up_jac"], G["lw_flux_up_jac"])
+
+    args = (bool(top_at_1), up(G["lw_tau"]), up(G["sw_ssa"]), up(G["sw_g"]), up(G["mu0"]), up(G["sw_alb_dir"]), up(G["sw_alb_dif"]), up(G["sw_inc_dir"]))
+    fs = be.sw_solver_2stream(*args)
+    ck.close("sw_flux_up", fs["flux_up"], G["sw_flux_up"]); ck.close("sw_flux_dn", fs["flux_dn"], G["sw_flux_dn"])
+    ck.close("sw_flux_dir", fs["flux_dir"], G["sw_flux_dir"])
+    fd = be.sw_solver_2stream(*args, inc_flux_dif=up(G["sw_inc_dif"]))
+    ck.close("sw_dif_flux_up", fd["flux_up"], G["sw_dif_flux_up"]); ck.close("sw_dif_flux_dn", fd["flux_dn"], G["sw_dif_flux_dn"])
+
+    t1, w1, g1 = up(G["lw_tau"].copy()), up(G["sw_ssa"].copy()), up(G["sw_g"].copy())
+    be.increment_2stream_by_2stream(t1, w1, g1, up(G["op_t2"]), up(G["op_w2"]), up(G["op_g2"]))
+    ck.close("op_inc2_tau", t1, G["op_inc2_tau"]); ck.close("op_inc2_ssa", w1, G["op_inc2_ssa"]); ck.close("op_inc2_g", g1, G["op_inc2_g"])
+    t1 = up(G["lw_tau"].copy()); be.increment_1scalar_by_1scalar(t1, up(G["op_t2"])); ck.close("op_inc1_tau", t1, G["op_inc1_tau"])
+    lims = up(G["op_lims"])
+    t1, w1, g1 = up(G["lw_tau"].copy()), up(G["sw_ssa"].copy()), up(G["sw_g"].copy())
+    be.inc_2stream_by_2stream_bybnd(t1, w1, g1, up(G["op_tb"]), up(G["op_wb"]), up(G["op_gb"]), lims)
+    ck.close("op_incb2_tau", t1, G["op_incb2_tau"]); ck.close("op_incb2_ssa", w1, G["op_incb2_ssa"]); ck.close("op_incb2_g", g1, G["op_incb2_g"])
+    t1 = up(G["lw_tau"].copy()); be.inc_1scalar_by_1scalar_bybnd(t1, up(G["op_tb"]), lims); ck.close("op_incb1_tau", t1, G["op_incb1_tau"])
+    t1, w1, g1 = up(G["lw_tau"].copy()), up(G["sw_ssa"].copy()), up(G["sw_g"].copy())
+    be.delta_scale_2str_k(t1, w1, g1)
+    ck.close("op_ds_tau", t1, G["op_ds_tau"]); ck.close("op_ds_ssa", w1, G["op_ds_ssa"]); ck.close("op_ds_g", g1, G["op_ds_g"])
+    return ck.worst
