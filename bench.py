@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py -- columns/sec of one full clear-sky LW+SW solve (140 layers x 256 g-points) on N MI355X.
+
+A step = gas optics (interpolation, major+minor absorption, Rayleigh) -> Planck sources -> lw_solver_noscat ->
+sw_solver_2stream -> broadband flux reduction, on a synthetic RCEMIP atmosphere + synthetic k-distribution with
+the real shapes; inputs and LUTs are resident in HBM before the timed region starts.
+Columns shard over ranks (one process per GPU, weak scaling: --ncol columns PER GPU); the only collective is the
+all-gather of the packed broadband fluxes (7 x nlev x ncol words per rank) at the end of each step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, live HIP-event
+timing on the launch stream) and `cpu_baseline` (the oracle, a scalar CPU port, on a bounded column sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic words per (column, g-point) at nlay layers -- SURVEY.md section 8(d), DESIGN.md section 5
+def algo_words(nlay):
+    nlev = nlay + 1
+    return dict(
+        lw_gas_optics=nlay,                              # tau
+        lw_planck=2*nlay + 1 + 2,                        # lay_src, lev_src, sfc_src(+jac)
+        lw_solver=3*nlay + 1 + 2 + 2*nlev,               # 705 at nlay = 140
+        lw_reduce=2*nlev,
+        sw_gas_optics=3*nlay + 1,                        # tau, ssa, g, toa
+        sw_solver=3*nlay + 3 + 3*nlev,                   # 846 at nlay = 140
+        sw_reduce=3*nlev)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(args, kd_lw0, kd_sw0):
+    """The oracle (scalar C++ port of the reference CPU path, oracle/rrtmgp_oracle.cpp) on a bounded sample of the
+    same workload: `cpu_cols` columns in 12-column blocks like src_test/Radiation_solver.cpp:409, one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from rte_rrtmgp_cpp_amd import synthetic, pipeline
+    if not oracle_py.have("oracle"):
+        oracle_py.build(ref=False)
+    orc = oracle_py.CpuKernels("oracle", np.float64)
+    kd_lw, kd_sw = orc.upload_kdist(kd_lw0), orc.upload_kdist(kd_sw0)
+    ncols = args.cpu_cols
+    blocks = [synthetic.make_atmosphere(min(12, ncols - c0), args.nlay, nbnd_lw=kd_lw0.nbnd, nbnd_sw=kd_sw0.nbnd, seed=1234 + c0)
+              for c0 in range(0, ncols, 12)]
+    t0 = time.perf_counter()
+    for sub in blocks:
+        pipeline.solve_lw(orc, kd_lw, sub, do_broadband=True)
+        pipeline.solve_sw(orc, kd_sw, sub, do_broadband=True, fused_gas=False)
+    dt = time.perf_counter() - t0
+    return dict(value=ncols/dt, unit="columns/s", cores=1, kind="port",
+                sample=f"{ncols} columns x {args.nlay} layers x {kd_lw0.ngpt}+{kd_sw0.ngpt} g-points, LW+SW clear-sky, "
+                       f"12-column blocks, fp64, broadband mode, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncol", type=int, default=128*128, help="columns PER GPU (C4 = 128 x 128)")
+    ap.add_argument("--nlay", type=int, default=140)
+    ap.add_argument("--ngpt", type=int, default=256)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--broadband", action="store_true", help="fuse the g-point sum into the solvers (CPU-path semantics)")
+    ap.add_argument("--lw-variant", type=int, default=0)
+    ap.add_argument("--sw-variant", type=int, default=0)
+    ap.add_argument("--cpu-cols", type=int, default=1200, help="columns of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rte_rrtmgp_cpp_amd as R
+    from rte_rrtmgp_cpp_amd import synthetic, pipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    be = R.HipKernels(np_dtype, device)
+    be.set_variant(lw=args.lw_variant, sw=args.sw_variant)
+    nbnd = args.ngpt // 16
+    kd_lw0 = synthetic.make_kdist("lw", ngpt=args.ngpt, nbnd=nbnd)
+    kd_sw0 = synthetic.make_kdist("sw", ngpt=args.ngpt, nbnd=nbnd)
+    kd_lw, kd_sw = be.upload_kdist(kd_lw0), be.upload_kdist(kd_sw0)
+    # rank r owns global columns [r*ncol, (r+1)*ncol): different seed offset per rank, same generator
+    atm0 = synthetic.make_atmosphere(args.ncol, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234 + rank)
+    atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
+    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband)
+    gathered = None
+    if world > 1 and not args.no_gather:
+        gathered = torch.empty((world,) + tuple(solver.fluxes.shape), dtype=solver.fluxes.dtype, device=device)
+
+    def one_step():
+        F = solver.step()
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, F)
+
+    for _ in range(args.warmup):
+        one_step()
+    solver.enable_stage_events(args.steps)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        S = np_dtype().itemsize
+        ms = solver.stage_ms()
+        words = algo_words(args.nlay)
+        units = args.ncol * args.ngpt
+        kernels = {}
+        for st, w in words.items():
+            gbs = w * units * S / (ms[st]*1e-3) / 1e9
+            kernels[st] = dict(ms=round(ms[st], 4), algo_GB=round(w*units*S/1e9, 4), GBs=round(gbs, 1), frac=round(gbs/HBM_PEAK_GBS, 4))
+        single = {k: v for k, v in kernels.items() if k in ("lw_solver", "sw_solver", "lw_planck")}   # single-launch stages
+        dom = max(single, key=lambda k: single[k]["ms"])
+        finite = bool(torch.isfinite(solver.fluxes).all().item())
+        out = {
+            "metric": "columns/sec (LW+SW full solve, 140 lay x 256 gpt)",
+            "value": round(args.ncol * world * args.steps / dt, 1),
+            "unit": "columns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C4 synthetic {args.ncol} columns/GPU x {args.nlay} layers x {args.ngpt} g-points, "
+                                   f"LW+SW clear-sky, RCEMIP profile, synthetic k-distribution (real shapes)",
+                       "columns_per_gpu": args.ncol, "nlay": args.nlay, "ngpt": args.ngpt,
+                       "flux_mode": "broadband-fused" if args.broadband else "per-g-point + sum_broadband",
+                       "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dom]["frac"], "traffic": None,
+                         "algorithmic_bytes_per_launch": int(words[dom]*units*S), "avg_launch_ms": kernels[dom]["ms"]},
+            "stages": kernels,
+            "finite": finite,
+        }
+        if world == 1 and args.cpu_cols > 0:
+            out["cpu_baseline"] = cpu_baseline(args, kd_lw0, kd_sw0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

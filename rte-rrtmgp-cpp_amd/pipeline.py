@@ -13,6 +13,8 @@ oracle/oracle_py.py (numpy). This module never imports the oracle.
 """
 import numpy as np
 
+from ._ffi import BoolArg
+
 # Gauss-Jacobi-5 quadrature, R. J. Hogan 2023 (values as in /root/reference/src/Rte_lw.cpp:140-152); (n_angles, point)
 MAX_GAUSS_PTS = 4
 GAUSS_DS = np.array([
@@ -126,3 +128,111 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
         out.update(tau=tau, ssa=ssa, g=g, toa_src=toa_src, gpt_flux_up=r.get("flux_up"),
                    gpt_flux_dn=r.get("flux_dn"), gpt_flux_dir=r.get("flux_dir"))
     return out
+
+
+class ResidentSolver:
+    """One full clear-sky LW+SW solve per ``step()`` with every buffer allocated once (what a host model keeps
+    resident between radiation calls, cf. the cached subsets in /root/reference/src_test/Radiation_solver.cu:450-466).
+    HIP backend only; used by bench.py and the full-size tests. ``stage_events`` (torch.cuda.Event pairs on the
+    launch stream) give per-stage device durations without synchronising inside the step."""
+
+    STAGES = ("lw_gas_optics", "lw_planck", "lw_solver", "lw_reduce", "sw_gas_optics", "sw_solver", "sw_reduce")
+
+    def __init__(self, be, kd_lw, kd_sw, atm, do_broadband=False):
+        import torch
+        self.torch = torch
+        self.be, self.kd_lw, self.kd_sw, self.atm = be, kd_lw, kd_sw, atm
+        self.do_broadband = do_broadband
+        ncol, nlay = atm.ncol, atm.nlay
+        ng_l, ng_s = kd_lw.ngpt, kd_sw.ngpt
+        e = be.empty
+        self.col_dry = e((nlay, ncol))
+        self.lw = dict(tau=e((ng_l, nlay, ncol)), lay_src=e((ng_l, nlay, ncol)), lev_src=e((ng_l, nlay+1, ncol)),
+                       sfc_src=e((ng_l, ncol)), sfc_src_jac=e((ng_l, ncol)))
+        self.sw = dict(tau=e((ng_s, nlay, ncol)), ssa=e((ng_s, nlay, ncol)), g=e((ng_s, nlay, ncol)))
+        if not do_broadband:
+            self.lw.update(gpt_up=e((ng_l, nlay+1, ncol)), gpt_dn=e((ng_l, nlay+1, ncol)))
+            self.sw.update(gpt_up=e((ng_s, nlay+1, ncol)), gpt_dn=e((ng_s, nlay+1, ncol)), gpt_dir=e((ng_s, nlay+1, ncol)))
+        # packed broadband outputs: LW up/dn/net + SW up/dn/dir/net  (7, nlev, ncol) -> one all-gather
+        self.fluxes = e((7, nlay+1, ncol))
+        self.weights = be.asarray(np.ascontiguousarray(GAUSS_WTS[0, :1]))
+        self.gauss_Ds = be.asarray(GAUSS_DS)
+        self.secants = be.lw_secants_array(ncol, ng_l, 1, MAX_GAUSS_PTS, self.gauss_Ds)
+        self.sfc_emis_gpt = be.expand_and_transpose(kd_lw.band_lims_gpt, atm.emis_sfc, ng_l)
+        self.alb_dir = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dir, ng_s)
+        self.alb_dif = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dif, ng_s)
+        self.events = None
+
+    def enable_stage_events(self, nsteps):
+        ev = self.torch.cuda.Event
+        self.events = [{s: (ev(enable_timing=True), ev(enable_timing=True)) for s in self.STAGES} for _ in range(nsteps)]
+        self._istep = 0
+
+    def stage_ms(self):
+        out = {s: [] for s in self.STAGES}
+        for rec in self.events[:self._istep]:
+            for s, (a, b) in rec.items():
+                out[s].append(a.elapsed_time(b))
+        return {s: float(np.mean(v)) for s, v in out.items() if v}
+
+    def step(self):
+        be, atm = self.be, self.atm
+        rec = None
+        if self.events is not None and self._istep < len(self.events):
+            rec = self.events[self._istep]
+            self._istep += 1
+
+        def mark(stage, end=False):
+            if rec is not None:
+                rec[stage][1 if end else 0].record(self.torch.cuda.current_stream(be.device))
+
+        ncol, nlay = atm.ncol, atm.nlay
+        F = self.fluxes
+        for kind, kd, buf in (("lw", self.kd_lw, self.lw), ("sw", self.kd_sw, self.sw)):
+            mark(kind + "_gas_optics")
+            be._c("get_col_dry", ncol, nlay, atm.vmr["h2o"], atm.p_lev, self.col_dry)
+            col_gas = be.fill_gases(kd, atm.vmr, self.col_dry)
+            it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+            if kind == "lw":
+                buf["tau"].zero_()
+                be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                mark("lw_gas_optics", True)
+                mark("lw_planck")
+                be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm),
+                                         out=dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"],
+                                                  sfc_src_jac=buf["sfc_src_jac"]))
+                mark("lw_planck", True)
+                mark("lw_solver")
+                if self.do_broadband:
+                    be._c("lw_solver_noscat", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), 1, self.secants, self.weights,
+                          buf["tau"], buf["lay_src"], buf["lev_src"], self.sfc_emis_gpt, buf["sfc_src"], None, None, None,
+                          BoolArg(True), F[0], F[1], BoolArg(False), None, None)
+                else:
+                    be.lw_solver_noscat_into(atm.top_at_1, self.secants, self.weights, buf["tau"], buf["lay_src"],
+                                             buf["lev_src"], self.sfc_emis_gpt, buf["sfc_src"], buf["gpt_up"], buf["gpt_dn"])
+                mark("lw_solver", True)
+                mark("lw_reduce")
+                if not self.do_broadband:
+                    be.sum_broadband(buf["gpt_up"], out=F[0]); be.sum_broadband(buf["gpt_dn"], out=F[1])
+                be.net_broadband_precalc(F[1], F[0], out=F[2])
+                mark("lw_reduce", True)
+            else:
+                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, self.col_dry, buf["tau"], buf["ssa"], buf["g"])
+                toa = be.spread_col(ncol, kd.solar_source)
+                be.scaling_to_subset(toa, atm.tsi_scaling)
+                mark("sw_gas_optics", True)
+                mark("sw_solver")
+                if self.do_broadband:
+                    be._c("sw_solver_2stream", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), buf["tau"], buf["ssa"], buf["g"], atm.mu0,
+                          self.alb_dir, self.alb_dif, toa, None, None, None, BoolArg(False), None,
+                          BoolArg(True), F[3], F[4], F[5])
+                else:
+                    be.sw_solver_2stream_into(atm.top_at_1, buf["tau"], buf["ssa"], buf["g"], atm.mu0, self.alb_dir, self.alb_dif,
+                                              toa, buf["gpt_up"], buf["gpt_dn"], buf["gpt_dir"])
+                mark("sw_solver", True)
+                mark("sw_reduce")
+                if not self.do_broadband:
+                    be.sum_broadband(buf["gpt_up"], out=F[3]); be.sum_broadband(buf["gpt_dn"], out=F[4]); be.sum_broadband(buf["gpt_dir"], out=F[5])
+                be.net_broadband_precalc(F[4], F[3], out=F[6])
+                mark("sw_reduce", True)
+        return F
