@@ -38,58 +38,50 @@ namespace rrx
     // ---- vector-of-columns helpers: V consecutive columns handled by one lane ----
     template<typename F, int V> struct Vec { F v[V]; };
 
+    // V consecutive columns starting at p. The launchers only pick V > 1 when ncol % V == 0, so a lane's V columns
+    // are either all inside the array or the lane is inactive (and then loads a valid dummy address).
     template<typename F, int V>
-    __device__ __forceinline__ Vec<F,V> load_cols(const F* __restrict__ p, const int nvalid)
+    __device__ __forceinline__ Vec<F,V> load_cols(const F* __restrict__ p)
     {
-        // p points at the first of V consecutive columns; nvalid (1..V) of them exist.
         Vec<F,V> r;
         if constexpr (V == 1)
-        {
             r.v[0] = p[0];
-        }
         else
         {
-            if (nvalid == V)
-            {
-                typedef F vecT __attribute__((ext_vector_type(V)));
-                // rows are only guaranteed sizeof(F)-aligned when ncol % V != 0; the launcher picks V accordingly.
-                const vecT t = *reinterpret_cast<const vecT*>(p);
-                #pragma unroll
-                for (int i=0; i<V; ++i) r.v[i] = t[i];
-            }
-            else
-            {
-                #pragma unroll
-                for (int i=0; i<V; ++i) r.v[i] = p[i < nvalid ? i : 0];
-            }
+            typedef F vecT __attribute__((ext_vector_type(V)));
+            const vecT t = *reinterpret_cast<const vecT*>(p);
+            #pragma unroll
+            for (int i=0; i<V; ++i) r.v[i] = t[i];
         }
         return r;
     }
 
     template<typename F, int V>
-    __device__ __forceinline__ void store_cols(F* __restrict__ p, const Vec<F,V>& r, const int nvalid)
+    __device__ __forceinline__ void store_cols(F* __restrict__ p, const Vec<F,V>& r)
     {
         if constexpr (V == 1)
-        {
             p[0] = r.v[0];
-        }
         else
         {
-            if (nvalid == V)
-            {
-                typedef F vecT __attribute__((ext_vector_type(V)));
-                vecT t;
-                #pragma unroll
-                for (int i=0; i<V; ++i) t[i] = r.v[i];
-                *reinterpret_cast<vecT*>(p) = t;
-            }
-            else
-            {
-                #pragma unroll
-                for (int i=0; i<V; ++i) if (i < nvalid) p[i] = r.v[i];
-            }
+            typedef F vecT __attribute__((ext_vector_type(V)));
+            vecT t;
+            #pragma unroll
+            for (int i=0; i<V; ++i) t[i] = r.v[i];
+            *reinterpret_cast<vecT*>(p) = t;
         }
     }
+
+    // 1/x to ~1 ulp without the IEEE corner-case handling of a full division (operands here are finite, normal and
+    // well away from 0/inf: layer transmissivities, two-stream denominators): v_rcp + 2 Newton steps (f64), 1 (f32).
+    __device__ __forceinline__ double fast_rcp(const double x)
+    {
+        double r = __builtin_amdgcn_rcp(x);
+        double e = fma(-x, r, 1.0); r = fma(r, e, r);
+        e = fma(-x, r, 1.0); r = fma(r, e, r);
+        return r;
+    }
+    // fp32 kernels are HBM-bound with VALU to spare: keep the correctly rounded division there
+    __device__ __forceinline__ float fast_rcp(const float x) { return 1.0f / x; }
 
     inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
 }

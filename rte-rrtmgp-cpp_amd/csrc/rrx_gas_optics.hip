@@ -93,21 +93,21 @@ interpolation_kernel(
 
 
 // Per-workgroup index of the minor contributors overlapping each 16-g-point chunk, built in LDS.
-// lists[r][c][0] = count, lists[r][c][1..] = interval ids in ascending order (deterministic summation order,
-// identical to the reference's sequential loop over imnr).
+// Entry layout (ints): lists[r][c] = { count, then per item {imnr, gpt_start, gpt_end, kminor_start-1-gpt_start} }
+// in ascending imnr (deterministic summation order, identical to the reference's sequential loop over imnr).
 struct MinorIndex
 {
-    int* base; int stride_c; int stride_r;
-    __device__ int count(int r, int c) const { return base[r*stride_r + c*stride_c]; }
-    __device__ int item(int r, int c, int i) const { return base[r*stride_r + c*stride_c + 1 + i]; }
+    const int* base; int stride_c; int stride_r;
+    __device__ __forceinline__ int count(int r, int c) const { return base[r*stride_r + c*stride_c]; }
+    __device__ __forceinline__ const int* item(int r, int c, int i) const { return base + r*stride_r + c*stride_c + 1 + 4*i; }
 };
 
 __device__ inline MinorIndex build_minor_index(
         int* lds, const int nchunk, const int nmax,
-        const int nminorlower, const int* __restrict__ lim_lower,
-        const int nminorupper, const int* __restrict__ lim_upper)
+        const int nminorlower, const int* __restrict__ lim_lower, const int* __restrict__ kst_lower,
+        const int nminorupper, const int* __restrict__ lim_upper, const int* __restrict__ kst_upper)
 {
-    MinorIndex mi{lds, 1 + nmax, nchunk*(1 + nmax)};
+    MinorIndex mi{lds, 1 + 4*nmax, nchunk*(1 + 4*nmax)};
     const int tid = threadIdx.y*blockDim.x + threadIdx.x;
     const int nthr = blockDim.x*blockDim.y;
     for (int w = tid; w < 2*nchunk; w += nthr)
@@ -115,24 +115,35 @@ __device__ inline MinorIndex build_minor_index(
         const int r = w / nchunk, c = w % nchunk;
         const int n = r == 0 ? nminorlower : nminorupper;
         const int* lim = r == 0 ? lim_lower : lim_upper;
+        const int* kst = r == 0 ? kst_lower : kst_upper;
+        int* out = lds + r*mi.stride_r + c*mi.stride_c;
         int cnt = 0;
         for (int i=0; i<n; ++i)
         {
             const int lo = lim[2*i]-1, hi = lim[2*i+1];          // [lo, hi) zero-based
             if (lo < (c+1)*GCH && hi > c*GCH)
-                lds[r*mi.stride_r + c*mi.stride_c + 1 + cnt++] = i;
+            {
+                out[1 + 4*cnt + 0] = i; out[1 + 4*cnt + 1] = lo; out[1 + 4*cnt + 2] = hi;
+                out[1 + 4*cnt + 3] = kst[i]-1 - lo;
+                ++cnt;
+            }
         }
-        lds[r*mi.stride_r + c*mi.stride_c] = cnt;
+        out[0] = cnt;
     }
     __syncthreads();
     return mi;
 }
+
+constexpr int MAXI = 12;     // minor scalings cached in LDS per (thread, chunk); further ones are recomputed
 
 
 // MODE 0: tau += major + minor            (compute_tau_absorption, reference semantics: caller zeroes tau)
 // MODE 1: tau/ssa/g = fused absorption + Rayleigh + combine   (SW gas optics in one pass)
 // major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
 // minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
+// Assumes, like the reference's data (create_gpoint_flavor, src/Gas_optics_rrtmgp.cpp:331-363), that a minor
+// interval does not straddle bands of different flavor; if it does the flavor of its first g-point is used,
+// exactly as in the reference kernel.
 template<typename F, int MODE>
 __global__ void __launch_bounds__(256)
 tau_absorption_kernel(
@@ -152,12 +163,16 @@ tau_absorption_kernel(
         const F* __restrict__ krayl,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
 {
-    extern __shared__ int lds[];
+    extern __shared__ double lds_raw[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
-    const MinorIndex mi = build_minor_index(lds, nchunk, nmax, nminorlower, minor_limits_gpt_lower,
-                                            nminorupper, minor_limits_gpt_upper);
+    F* scal = reinterpret_cast<F*>(lds_raw);                                   // [MAXI][256]
+    int* lists = reinterpret_cast<int*>(scal + MAXI*256);
+    const MinorIndex mi = build_minor_index(lists, nchunk, nmax,
+            nminorlower, minor_limits_gpt_lower, kminor_start_lower,
+            nminorupper, minor_limits_gpt_upper, kminor_start_upper);
 
+    const int tid = threadIdx.y*blockDim.x + threadIdx.x;
     const int icol = blockIdx.x*blockDim.x + threadIdx.x;
     const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
@@ -167,7 +182,9 @@ tau_absorption_kernel(
     const int itropo = tropo[idx] ? 0 : 1;
     const int jt = jtemp[idx];
     const int jp = jpress[idx] + itropo;
-    const size_t s_eta = ntemp, s_prs = size_t(ntemp)*neta, s_gpt = size_t(ntemp)*neta*(npres+1);
+    const int s_eta = ntemp, s_prs = ntemp*neta;
+    const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
+    const int tn = ntemp*neta;
 
     const F pl = play[idx], tl = tlay[idx];
     const F cdry0 = col_gas[idx];                         // col_gas(:,:,0) = col_dry
@@ -175,131 +192,107 @@ tau_absorption_kernel(
     F ray_fac = F(0.);
     if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
 
+    const F* kminor = itropo == 0 ? kminor_lower : kminor_upper;
+    const Bool* swd = itropo == 0 ? minor_scales_with_density_lower : minor_scales_with_density_upper;
+    const Bool* sbc = itropo == 0 ? scale_by_complement_lower : scale_by_complement_upper;
+    const int* imn = itropo == 0 ? idx_minor_lower : idx_minor_upper;
+    const int* ims = itropo == 0 ? idx_minor_scaling_lower : idx_minor_scaling_upper;
+
+    auto minor_scaling = [&](const int imnr) -> F
+    {
+        F scaling = col_gas[idx + size_t(imn[imnr])*ncl];
+        if (swd[imnr])
+        {
+            scaling *= F(0.01) * pl / tl;
+            if (ims[imnr] > 0)
+            {
+                const F vmr_fact = F(1.) / cdry0;
+                const F dry_fact = F(1.) / (F(1.) + ch2o * vmr_fact);
+                const F x = col_gas[idx + size_t(ims[imnr])*ncl] * vmr_fact * dry_fact;
+                scaling *= sbc[imnr] ? (F(1.) - x) : x;
+            }
+        }
+        return scaling;
+    };
+
+    // interpolation state of the current flavor
     int cur_flav = -1;
-    F fm[8], cm[2], fmn[4];
-    int je[2];
+    F fm0=0, fm1=0, fm2=0, fm3=0, fm4=0, fm5=0, fm6=0, fm7=0, cm0=0, cm1=0, fn0=0, fn1=0, fn2=0, fn3=0;
+    int o00=0, o01=0, o10=0, o11=0;            // kmajor offsets (without g-point) for the two temperatures
+    int m0a=0, m0b=0, m1a=0, m1b=0;            // kminor / krayl offsets
+
+    auto load_flavor = [&](const int iflav)
+    {
+        cur_flav = iflav;
+        const size_t cell = idx + size_t(iflav)*ncl;
+        const F* f = fmajor + 8*cell;
+        fm0=f[0]; fm1=f[1]; fm2=f[2]; fm3=f[3]; fm4=f[4]; fm5=f[5]; fm6=f[6]; fm7=f[7];
+        cm0 = col_mix[2*cell]; cm1 = col_mix[2*cell+1];
+        const int je0 = jeta[2*cell], je1 = jeta[2*cell+1];
+        const F* fn = fminor + 4*cell;
+        fn0=fn[0]; fn1=fn[1]; fn2=fn[2]; fn3=fn[3];
+        o00 = (jt-1) + (je0-1)*s_eta + (jp-1)*s_prs;  o01 = o00 + s_prs;
+        o10 =  jt    + (je1-1)*s_eta + (jp-1)*s_prs;  o11 = o10 + s_prs;
+        m0a = (jt-1) + (je0-1)*ntemp; m0b = m0a + ntemp;
+        m1a =  jt    + (je1-1)*ntemp; m1b = m1a + ntemp;
+    };
 
     for (int c=0; c<nchunk; ++c)
     {
         const int c0 = c*GCH;
-        F acc[GCH], ray[GCH];
+        const int n = mi.count(itropo, c);
 
-        // ---- major species
-        #pragma unroll
-        for (int u=0; u<GCH; ++u)
+        // per-cell scaling of every minor contributor of this chunk, cached in LDS (dynamic indexing)
+        for (int i=0; i<min(n, MAXI); ++i)
+            scal[i*256 + tid] = minor_scaling(mi.item(itropo, c, i)[0]);
+
+        const int gend = min(c0 + GCH, ngpt);
+        #pragma unroll 2
+        for (int ig=c0; ig<gend; ++ig)
         {
-            const int ig = min(c0 + u, ngpt-1);
             const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
-            if (iflav != cur_flav)
-            {
-                cur_flav = iflav;
-                const size_t cell = idx + iflav*ncl;
-                #pragma unroll
-                for (int i=0; i<8; ++i) fm[i] = fmajor[8*cell + i];
-                cm[0] = col_mix[2*cell]; cm[1] = col_mix[2*cell+1];
-                je[0] = jeta[2*cell]; je[1] = jeta[2*cell+1];
-                if constexpr (MODE == 1)
-                {
-                    #pragma unroll
-                    for (int i=0; i<4; ++i) fmn[i] = fminor[4*cell + i];
-                }
-            }
-            F t = F(0.);
-            #pragma unroll
-            for (int i=0; i<2; ++i)
-            {
-                const size_t b = (jt-1+i) + size_t(ig)*s_gpt;
-                t += cm[i] *
-                    (fm[i*4+0] * kmajor[b + (je[i]-1)*s_eta + (jp-1)*s_prs] +
-                     fm[i*4+1] * kmajor[b +  je[i]   *s_eta + (jp-1)*s_prs] +
-                     fm[i*4+2] * kmajor[b + (je[i]-1)*s_eta +  jp   *s_prs] +
-                     fm[i*4+3] * kmajor[b +  je[i]   *s_eta +  jp   *s_prs]);
-            }
-            acc[u] = t;
-            if constexpr (MODE == 1)
-            {
-                const F* k = krayl + size_t(itropo)*ntemp*neta*ngpt + size_t(ig)*ntemp*neta;
-                ray[u] = ray_fac *
-                    (fmn[0] * k[(jt-1) + (je[0]-1)*ntemp] +
-                     fmn[1] * k[(jt-1) +  je[0]   *ntemp] +
-                     fmn[2] * k[ jt    + (je[1]-1)*ntemp] +
-                     fmn[3] * k[ jt    +  je[1]   *ntemp]);
-            }
-        }
+            if (iflav != cur_flav) load_flavor(iflav);
 
-        // ---- minor species of this cell's regime (lower: r=0, upper: r=1)
-        for (int r=0; r<2; ++r)
-        {
-            const int n = mi.count(r, c);
-            const F* kminor = r == 0 ? kminor_lower : kminor_upper;
-            const int* lim = r == 0 ? minor_limits_gpt_lower : minor_limits_gpt_upper;
-            const Bool* swd = r == 0 ? minor_scales_with_density_lower : minor_scales_with_density_upper;
-            const Bool* sbc = r == 0 ? scale_by_complement_lower : scale_by_complement_upper;
-            const int* imn = r == 0 ? idx_minor_lower : idx_minor_upper;
-            const int* ims = r == 0 ? idx_minor_scaling_lower : idx_minor_scaling_upper;
-            const int* kst = r == 0 ? kminor_start_lower : kminor_start_upper;
-            for (int q=0; q<n; ++q)
-            {
-                const int imnr = mi.item(r, c, q);
-                if (itropo != r) continue;
+            const F* k = kmajor + size_t(ig)*s_gpt;
+            F t = cm0 * (fm0*k[o00] + fm1*k[o00 + s_eta] + fm2*k[o01] + fm3*k[o01 + s_eta])
+                + cm1 * (fm4*k[o10] + fm5*k[o10 + s_eta] + fm6*k[o11] + fm7*k[o11 + s_eta]);
 
-                F scaling = col_gas[idx + size_t(imn[imnr])*ncl];
-                if (swd[imnr])
+            for (int i=0; i<n; ++i)
+            {
+                const int* it = mi.item(itropo, c, i);
+                if (ig >= it[1] && ig < it[2])
                 {
-                    scaling *= F(0.01) * pl / tl;
-                    if (ims[imnr] > 0)
+                    const F sc = i < MAXI ? scal[i*256 + tid] : minor_scaling(it[0]);
+                    const F* km = kminor + size_t(ig + it[3])*tn;
+                    const int mflav = gpoint_flavor[2*it[1] + itropo] - 1;
+                    F kk;
+                    if (mflav == cur_flav)
+                        kk = fn0*km[m0a] + fn1*km[m0b] + fn2*km[m1a] + fn3*km[m1b];
+                    else
                     {
-                        const F vmr_fact = F(1.) / cdry0;
-                        const F dry_fact = F(1.) / (F(1.) + ch2o * vmr_fact);
-                        const F x = col_gas[idx + size_t(ims[imnr])*ncl] * vmr_fact * dry_fact;
-                        scaling *= sbc[imnr] ? (F(1.) - x) : x;
+                        const size_t cell = idx + size_t(mflav)*ncl;
+                        const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
+                        const F* fn = fminor + 4*cell;
+                        kk = fn[0]*km[(jt-1) + (j0-1)*ntemp] + fn[1]*km[(jt-1) + j0*ntemp]
+                           + fn[2]*km[ jt    + (j1-1)*ntemp] + fn[3]*km[ jt    + j1*ntemp];
                     }
-                }
-                const int gpt_start = lim[2*imnr]-1;
-                const int gpt_end = lim[2*imnr+1];
-                const int iflav = gpoint_flavor[2*gpt_start + r] - 1;
-                const size_t cell = idx + iflav*ncl;
-                const F f0 = fminor[4*cell], f1 = fminor[4*cell+1], f2 = fminor[4*cell+2], f3 = fminor[4*cell+3];
-                const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
-                const int koff = kst[imnr]-1 - gpt_start;
-
-                #pragma unroll
-                for (int u=0; u<GCH; ++u)
-                {
-                    const int ig = c0 + u;
-                    if (ig >= gpt_start && ig < gpt_end)
-                    {
-                        const size_t kb = size_t(ig + koff)*ntemp*neta;
-                        const F k =
-                            f0 * kminor[(jt-1) + (j0-1)*ntemp + kb] +
-                            f1 * kminor[(jt-1) +  j0   *ntemp + kb] +
-                            f2 * kminor[ jt    + (j1-1)*ntemp + kb] +
-                            f3 * kminor[ jt    +  j1   *ntemp + kb];
-                        acc[u] += k * scaling;
-                    }
+                    t += kk * sc;
                 }
             }
-        }
 
-        // ---- write out
-        #pragma unroll
-        for (int u=0; u<GCH; ++u)
-        {
-            const int ig = c0 + u;
-            if (ig < ngpt)
+            const size_t o = idx + size_t(ig)*ncl;
+            if constexpr (MODE == 0)
             {
-                const size_t o = idx + size_t(ig)*ncl;
-                if constexpr (MODE == 0)
-                {
-                    tau[o] += acc[u];
-                }
-                else
-                {
-                    const F tt = acc[u] + ray[u];
-                    tau[o] = tt;
-                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
-                    g[o] = F(0.);
-                }
+                tau[o] += t;
+            }
+            else
+            {
+                const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(ig)*tn;
+                const F ray = ray_fac * (fn0*kr[m0a] + fn1*kr[m0b] + fn2*kr[m1a] + fn3*kr[m1b]);
+                const F tt = t + ray;
+                tau[o] = tt;
+                ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
+                g[o] = F(0.);
             }
         }
     }
@@ -393,9 +386,14 @@ struct CellInterp
     }
 };
 
+constexpr int PL = 8;            // layers per Planck workgroup (block = 64 columns x PL layers)
+
 // /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:196-314
+// The reference recomputes the Planck fraction of the layer below for every level source (16 LUT gathers per
+// cell). Here a workgroup of 64 columns x 8 layers exchanges the fractions through LDS in chunks of 16 g-points,
+// so only the first layer of each workgroup recomputes its neighbour (9 gathers per cell on average).
 template<typename F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64*PL)
 planck_source_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp, const int nPlanckTemp,
         const F* __restrict__ tlay, const F* __restrict__ tlev, const F* __restrict__ tsfc, const int sfc_lay,
@@ -406,9 +404,15 @@ planck_source_kernel(
         const int* __restrict__ gpoint_flavor,
         F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac)
 {
-    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
-    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
-    if (icol >= ncol || ilay >= nlay) return;
+    extern __shared__ double lds_raw[];
+    F* pf = reinterpret_cast<F*>(lds_raw);            // [GCH][PL+1][64]; slot 0 = layer below the workgroup
+
+    const int tx = threadIdx.x, ly = threadIdx.y;
+    const int icol_raw = blockIdx.x*64 + tx;
+    const int ilay_raw = blockIdx.y*PL + ly;
+    const bool active = icol_raw < ncol && ilay_raw < nlay;
+    const int icol = min(icol_raw, ncol-1);
+    const int ilay = min(ilay_raw, nlay-1);
 
     const size_t ncl = size_t(ncol)*nlay;
     const size_t ncv = size_t(ncol)*(nlay+1);
@@ -419,9 +423,10 @@ planck_source_kernel(
     const int itropo = tropo[idx] ? 0 : 1;
     CellInterp<F> own, prev;
     own.jt = jtemp[idx]; own.jp = jpress[idx] + itropo;
-    int itropo_m1 = 0;
     const bool has_prev = ilay > 0;
-    if (has_prev)
+    const bool halo = ly == 0 && has_prev;             // this thread also computes the fraction of layer ilay-1
+    int itropo_m1 = 0;
+    if (halo)
     {
         itropo_m1 = tropo[idx - ncol] ? 0 : 1;
         prev.jt = jtemp[idx - ncol]; prev.jp = jpress[idx - ncol] + itropo_m1;
@@ -429,49 +434,64 @@ planck_source_kernel(
     const F t_lay = tlay[idx], t_lev = tlev[idx];
     const bool is_last = ilay == nlay-1;
     const bool is_sfc = ilay == sfc_lay-1;
-    const F t_levp = is_last ? tlev[idx + ncol] : F(0.);
-    const F t_sfc = is_sfc ? tsfc[icol] : F(0.);
+    const F t_levp = tlev[idx + ncol];
+    const F t_sfc = tsfc[icol];
 
     int cur_flav = -1, cur_flav_m1 = -1, cur_bnd = -1;
     F b_lay = 0, b_lev = 0, b_levp = 0, b_sfc = 0, b_sfc2 = 0;
 
-    for (int ig=0; ig<ngpt; ++ig)
+    for (int c0=0; c0<ngpt; c0+=GCH)
     {
-        const int ibnd = gpoint_bands[ig] - 1;
-        if (ibnd != cur_bnd)
+        const int gend = min(c0 + GCH, ngpt);
+        for (int ig=c0; ig<gend; ++ig)
         {
-            cur_bnd = ibnd;
-            const F* tp = totplnk + size_t(ibnd)*nPlanckTemp;
-            b_lay = interp1d(t_lay, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
-            b_lev = interp1d(t_lev, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
-            if (is_last) b_levp = interp1d(t_levp, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
-            if (is_sfc)
+            const int u = ig - c0;
+            const F* p = pfracin + size_t(ig)*s_gpt;
+            const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
+            if (iflav != cur_flav) { cur_flav = iflav; own.load(idx + iflav*ncl, fmajor, jeta); }
+            pf[(u*(PL+1) + ly+1)*64 + tx] = own.pfrac(p, s_eta, s_prs);
+            if (halo)
             {
-                b_sfc  = interp1d(t_sfc              , temp_ref_min, totplnk_delta, nPlanckTemp, tp);
-                b_sfc2 = interp1d(t_sfc + delta_Tsurf, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                const int iflav_m1 = gpoint_flavor[itropo_m1 + 2*ig] - 1;
+                if (iflav_m1 != cur_flav_m1) { cur_flav_m1 = iflav_m1; prev.load(idx - ncol + iflav_m1*ncl, fmajor, jeta); }
+                pf[(u*(PL+1))*64 + tx] = prev.pfrac(p, s_eta, s_prs);
             }
         }
-        const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
-        if (iflav != cur_flav) { cur_flav = iflav; own.load(idx + iflav*ncl, fmajor, jeta); }
-        const F* p = pfracin + size_t(ig)*s_gpt;
-        const F pfrac = own.pfrac(p, s_eta, s_prs);
+        __syncthreads();
 
-        lay_src[idx + size_t(ig)*ncl] = pfrac * b_lay;
-
-        F lev_val = pfrac * b_lev;
-        if (has_prev)
+        for (int ig=c0; ig<gend; ++ig)
         {
-            const int iflav_m1 = gpoint_flavor[itropo_m1 + 2*ig] - 1;
-            if (iflav_m1 != cur_flav_m1) { cur_flav_m1 = iflav_m1; prev.load(idx - ncol + iflav_m1*ncl, fmajor, jeta); }
-            lev_val = sqrt(pfrac * prev.pfrac(p, s_eta, s_prs)) * b_lev;
+            const int u = ig - c0;
+            const int ibnd = gpoint_bands[ig] - 1;
+            if (ibnd != cur_bnd)
+            {
+                cur_bnd = ibnd;
+                const F* tp = totplnk + size_t(ibnd)*nPlanckTemp;
+                b_lay = interp1d(t_lay, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                b_lev = interp1d(t_lev, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                if (is_last) b_levp = interp1d(t_levp, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                if (is_sfc)
+                {
+                    b_sfc  = interp1d(t_sfc              , temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                    b_sfc2 = interp1d(t_sfc + delta_Tsurf, temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                }
+            }
+            if (active)
+            {
+                const F pfrac = pf[(u*(PL+1) + ly+1)*64 + tx];
+                lay_src[idx + size_t(ig)*ncl] = pfrac * b_lay;
+                F lev_val = pfrac * b_lev;
+                if (has_prev) lev_val = sqrt(pfrac * pf[(u*(PL+1) + ly)*64 + tx]) * b_lev;
+                lev_src[idx + size_t(ig)*ncv] = lev_val;
+                if (is_last) lev_src[idx + ncol + size_t(ig)*ncv] = pfrac * b_levp;
+                if (is_sfc)
+                {
+                    sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
+                    sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
+                }
+            }
         }
-        lev_src[idx + size_t(ig)*ncv] = lev_val;
-        if (is_last) lev_src[idx + ncol + size_t(ig)*ncv] = pfrac * b_levp;
-        if (is_sfc)
-        {
-            sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
-            sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
-        }
+        __syncthreads();
     }
 }
 
@@ -522,7 +542,7 @@ int tau_absorption_impl(
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = std::max(nminorlower, nminorupper);
-    const size_t lds = size_t(2)*nchunk*(1 + nmax)*sizeof(int);
+    const size_t lds = size_t(MAXI)*256*sizeof(F) + size_t(2)*nchunk*(1 + 4*nmax)*sizeof(int);
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
@@ -636,7 +656,7 @@ int rrx_compute_planck_source##SFX( \
     RRX_TRY \
     (void)nbnd; (void)nflav; (void)band_lims_gpt; \
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
-    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, 4)), dim3(64, 4), 0, static_cast<hipStream_t>(stream)>>>( \
+    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F), static_cast<hipStream_t>(stream)>>>( \
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
             gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac); \
     RRX_CATCH("rrx_compute_planck_source") \

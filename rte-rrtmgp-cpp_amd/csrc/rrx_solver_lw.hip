@@ -15,10 +15,13 @@
 #include "rrx_common.h"
 #include "rrx_hip.h"
 
+#pragma clang fp contract(fast)
+
 namespace
 {
 using namespace rrx;
 
+int g_lw_sync = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
 constexpr int CL = 8;    // column lanes
 constexpr int LL = 8;    // level lanes
 
@@ -30,7 +33,7 @@ lw_noscat_scan_kernel(
         const F* __restrict__ tau, const F* __restrict__ lay_source, const F* __restrict__ lev_source,
         const F* __restrict__ sfc_emis, const F* __restrict__ sfc_src, const F* __restrict__ inc_flux,
         F* __restrict__ flux_up, F* __restrict__ flux_dn,
-        const F* __restrict__ sfc_src_jac, F* __restrict__ flux_up_jac)
+        const F* __restrict__ sfc_src_jac, F* __restrict__ flux_up_jac, const int sync_waves)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -38,14 +41,15 @@ lw_noscat_scan_kernel(
     const int ll = lane >> 3;
     const int igpt = blockIdx.y;
     const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    // The two waves that share each 128-B line (8 columns x 8 B = 64 B per wave when V = 1) must issue their load
+    // bursts together, or the second half of every line is fetched from HBM again once L2 has turned over
+    // (measured: +26 % FETCH_SIZE without the barrier). No thread leaves before the barrier.
+    if (sync_waves) __syncthreads();
     if (wave_col0 >= ncol) return;                    // wave-uniform
 
     int icol = wave_col0 + cl*V;
-    int nvalid = ncol - icol;                         // columns this lane really owns
-    const bool active = nvalid > 0;
-    if (!active) { icol = wave_col0; nvalid = 1; }    // harmless duplicate loads, no stores
-    if (nvalid > V) nvalid = V;
-    const int nld = active ? nvalid : 1;
+    const bool active = icol < ncol;                  // all V columns exist (ncol % V == 0) or none
+    if (!active) icol = wave_col0;                    // harmless duplicate loads, no stores
 
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
@@ -57,7 +61,7 @@ lw_noscat_scan_kernel(
     const F eps = Lim<F>::eps();
     const F tau_thres = sqrt(sqrt(eps));
 
-    const Vec<F,V> D = load_cols<F,V>(secants + sfc_idx + size_t(imu)*ncl*ngpt, nld);
+    const Vec<F,V> D = load_cols<F,V>(secants + sfc_idx + size_t(imu)*ncl*ngpt);
     const F w = weights[imu];
 
     const int t0 = ll*K;
@@ -71,7 +75,7 @@ lw_noscat_scan_kernel(
     {
         const int t = min(t0 + j, nlay);
         const int ml = top_at_1 ? t : nlay - t;
-        lv[j] = load_cols<F,V>(lev_source + lev_base + size_t(ml)*ncl, nld);
+        lv[j] = load_cols<F,V>(lev_source + lev_base + size_t(ml)*ncl);
     }
 
     F A[V], Bdn[V], Bup[V];
@@ -85,8 +89,8 @@ lw_noscat_scan_kernel(
         const bool valid = s < nlay;
         const int sc = min(s, nlay-1);
         const int ml = top_at_1 ? sc : nlay-1-sc;
-        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl, nld);
-        const Vec<F,V> ls = load_cols<F,V>(lay_source + lay_base + size_t(ml)*ncl, nld);
+        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl);
+        const Vec<F,V> ls = load_cols<F,V>(lay_source + lay_base + size_t(ml)*ncl);
 
         #pragma unroll
         for (int v=0; v<V; ++v)
@@ -100,7 +104,7 @@ lw_noscat_scan_kernel(
             const F tau_loc = tv.v[v] * D.v[v];
             const F trans = exp(-tau_loc);
             const F fact = tau_loc > tau_thres ?
-                (F(1.) - trans) / tau_loc - trans :
+                (F(1.) - trans) * fast_rcp(tau_loc) - trans :
                 tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
             const F omt = F(1.) - trans;
             const F s_dn = omt * lev_below + F(2.) * fact * (ls.v[v] - lev_below);
@@ -116,12 +120,12 @@ lw_noscat_scan_kernel(
         }
     }
 
-    const Vec<F,V> emis = load_cols<F,V>(sfc_emis + sfc_idx, nld);
-    const Vec<F,V> ssrc = load_cols<F,V>(sfc_src + sfc_idx, nld);
+    const Vec<F,V> emis = load_cols<F,V>(sfc_emis + sfc_idx);
+    const Vec<F,V> ssrc = load_cols<F,V>(sfc_src + sfc_idx);
     Vec<F,V> inc;
-    if (inc_flux != nullptr) inc = load_cols<F,V>(inc_flux + sfc_idx, nld);
+    if (inc_flux != nullptr) inc = load_cols<F,V>(inc_flux + sfc_idx);
     Vec<F,V> sjac;
-    if constexpr (JAC) sjac = load_cols<F,V>(sfc_src_jac + sfc_idx, nld);
+    if constexpr (JAC) sjac = load_cols<F,V>(sfc_src_jac + sfc_idx);
 
     F dn_in[V], up_in[V], jac_in[V];
 
@@ -161,57 +165,57 @@ lw_noscat_scan_kernel(
         if constexpr (JAC) jac_in[v] = ae * emis.v[v] * sjac.v[v];
     }
 
-    // ---- replay this lane's K layers and store its K levels
-    const F scale = pi * w;
-    Vec<F,V> oup[K], odn[K], ojac[K];
-
-    #pragma unroll
-    for (int v=0; v<V; ++v)
-    {
-        F dn = dn_in[v];
-        #pragma unroll
-        for (int j=0; j<K; ++j)
-        {
-            odn[j].v[v] = scale * dn;
-            dn = tr[j][v]*dn + sdn[j][v];
-        }
-        F up = up_in[v];
-        F jc = JAC ? jac_in[v] : F(0.);
-        #pragma unroll
-        for (int j=K-1; j>=0; --j)
-        {
-            up = tr[j][v]*up + sup[j][v];
-            oup[j].v[v] = scale * up;
-            if constexpr (JAC) { jc = tr[j][v]*jc; ojac[j].v[v] = scale * jc; }
-        }
-    }
-
+    // ---- replay this lane's K layers and store its K levels (each value is stored as soon as it exists: no staging)
     if (!active) return;
+    const F scale = pi * w;
 
-    #pragma unroll
-    for (int j=0; j<K; ++j)
+    auto put = [&](F* __restrict__ arr, const int j, Vec<F,V> val)
     {
         const int t = t0 + j;
         if (t <= nlay)
         {
             const int ml = top_at_1 ? t : nlay - t;
-            const size_t o = lev_base + size_t(ml)*ncl;
+            F* o = arr + lev_base + size_t(ml)*ncl;
             if constexpr (ACC)
             {
-                const Vec<F,V> pu = load_cols<F,V>(flux_up + o, nvalid);
-                const Vec<F,V> pd = load_cols<F,V>(flux_dn + o, nvalid);
+                const Vec<F,V> prev = load_cols<F,V>(o);
                 #pragma unroll
-                for (int v=0; v<V; ++v) { oup[j].v[v] += pu.v[v]; odn[j].v[v] += pd.v[v]; }
-                if constexpr (JAC)
-                {
-                    const Vec<F,V> pj = load_cols<F,V>(flux_up_jac + o, nvalid);
-                    #pragma unroll
-                    for (int v=0; v<V; ++v) ojac[j].v[v] += pj.v[v];
-                }
+                for (int v=0; v<V; ++v) val.v[v] += prev.v[v];
             }
-            store_cols<F,V>(flux_up + o, oup[j], nvalid);
-            store_cols<F,V>(flux_dn + o, odn[j], nvalid);
-            if constexpr (JAC) store_cols<F,V>(flux_up_jac + o, ojac[j], nvalid);
+            store_cols<F,V>(o, val);
+        }
+    };
+
+    {
+        F dn[V];
+        #pragma unroll
+        for (int v=0; v<V; ++v) dn[v] = dn_in[v];
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            Vec<F,V> o;
+            #pragma unroll
+            for (int v=0; v<V; ++v) { o.v[v] = scale * dn[v]; dn[v] = tr[j][v]*dn[v] + sdn[j][v]; }
+            put(flux_dn, j, o);
+        }
+    }
+    {
+        F up[V], jc[V];
+        #pragma unroll
+        for (int v=0; v<V; ++v) { up[v] = up_in[v]; jc[v] = JAC ? jac_in[v] : F(0.); }
+        #pragma unroll
+        for (int j=K-1; j>=0; --j)
+        {
+            Vec<F,V> o, oj;
+            #pragma unroll
+            for (int v=0; v<V; ++v)
+            {
+                up[v] = tr[j][v]*up[v] + sup[j][v];
+                o.v[v] = scale * up[v];
+                if constexpr (JAC) { jc[v] = tr[j][v]*jc[v]; oj.v[v] = scale * jc[v]; }
+            }
+            put(flux_up, j, o);
+            if constexpr (JAC) put(flux_up_jac, j, oj);
         }
     }
 }
@@ -328,15 +332,16 @@ void launch_scan_k(
 {
 #define RRX_LW_ARGS ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, sfc_src_jac, flux_up_jac
+#define RRX_LW_KARGS RRX_LW_ARGS, g_lw_sync
     if (jac)
     {
-        if (acc) lw_noscat_scan_kernel<F,V,K,true,true><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
-        else     lw_noscat_scan_kernel<F,V,K,true,false><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+        if (acc) lw_noscat_scan_kernel<F,V,K,true,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        else     lw_noscat_scan_kernel<F,V,K,true,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
     }
     else
     {
-        if (acc) lw_noscat_scan_kernel<F,V,K,false,true><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
-        else     lw_noscat_scan_kernel<F,V,K,false,false><<<grid, 256, 0, st>>>(RRX_LW_ARGS);
+        if (acc) lw_noscat_scan_kernel<F,V,K,false,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        else     lw_noscat_scan_kernel<F,V,K,false,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
     }
 }
 
@@ -356,7 +361,7 @@ bool launch_scan(
     return false;
 }
 
-int g_lw_variant = 0;   // 0 = auto (scan), 1 = force serial, 2 = scan with V=1
+int g_lw_variant = 0;   // 0 = auto (scan), 1 = force serial, 2 = scan with V=1, 3 = scan with 128-B segments
 
 #define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac
@@ -390,15 +395,20 @@ int lw_solver_noscat_impl(
         up = ws; dn = ws + nlevcol*ngpt;
     }
 
-    constexpr int VMAX = (sizeof(F) == 8) ? 2 : 4;
+    // columns per lane: VDEF*8 lanes*sizeof(F) = 64-B row segments and <= 176 VGPRs (2 waves/SIMD); the wide form
+    // (128-B segments, 1 wave/SIMD) measured the same or slower and is kept as variant 3 for A/B runs.
+    constexpr int VDEF = (sizeof(F) == 8) ? 1 : 2;
+    constexpr int VMAX = 2*VDEF;
     for (int imu=0; imu<nmus; ++imu)
     {
         const bool acc = imu > 0;
         bool done = false;
         if (g_lw_variant != 1)
         {
-            if (g_lw_variant != 2 && ncol % VMAX == 0)
+            if (g_lw_variant == 3 && ncol % VMAX == 0)
                 done = launch_scan<F,VMAX>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (g_lw_variant != 2 && ncol % VDEF == 0)
+                done = launch_scan<F,VDEF>(st, jac, acc, RRX_LW_ARGS_CALL);
             else
                 done = launch_scan<F,1>(st, jac, acc, RRX_LW_ARGS_CALL);
         }

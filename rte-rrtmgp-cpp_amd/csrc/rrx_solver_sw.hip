@@ -15,23 +15,31 @@
 #include "rrx_common.h"
 #include "rrx_hip.h"
 
+#pragma clang fp contract(fast)
+
 namespace
 {
 using namespace rrx;
 
 constexpr int CL = 8;
 constexpr int LL = 8;
+constexpr int LOADG = 6;   // layers per load group
+#ifndef RRX_SW_MINWAVES
+#define RRX_SW_MINWAVES 1
+#endif
 
 template<typename F>
 struct TwoStream { F r_dif, t_dif, r_dir, t_dir, t_noscat; };
 
-// /root/reference/src_kernels_cuda/rte_solver_kernels.cu:543-592 (Zdunkowski PIFM two-stream, Ukkonen clamps)
+// /root/reference/src_kernels_cuda/rte_solver_kernels.cu:543-592 (Zdunkowski PIFM two-stream, Ukkonen clamps).
+// Same formulas; the three divisions per cell (1/mu0, rt_term, /fact) are replaced by one hoisted reciprocal of mu0
+// and ONE Newton reciprocal x = 1/(D*fact): rt_term = x*fact, rt_term2 = ssa*x (fp64 vector rate is the scarce
+// resource of this kernel: DESIGN.md section "sw_solver_2stream").
 template<typename F>
-__device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, const F g, const F mu0)
+__device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, const F g, const F mu0, const F mu0_inv)
 {
     TwoStream<F> o;
     const F tmin = Lim<F>::eps();
-    const F mu0_inv = F(1.)/mu0;
     const F gamma1 = (F(8.) - ssa * (F(5.) + F(3.) * g)) * F(.25);
     const F gamma2 = F(3.) * (ssa * (F(1.) - g)) * F(.25);
     const F gamma3 = (F(2.) - F(3.) * mu0 * g) * F(.25);
@@ -41,21 +49,33 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
     const F k = sqrt(max((gamma1 - gamma2) * (gamma1 + gamma2), Lim<F>::k_min()));
     const F exp_minusktau = exp(-tau * k);
     const F exp_minus2ktau = exp_minusktau * exp_minusktau;
-    const F rt_term = F(1.) / (k * (F(1.) + exp_minus2ktau) + gamma1 * (F(1.) - exp_minus2ktau));
+    const F k_mu = k * mu0;
+    const F omk2 = F(1.) - k_mu*k_mu;
+    const F fact = (abs(omk2) > tmin) ? omk2 : tmin;
+    const F D = k * (F(1.) + exp_minus2ktau) + gamma1 * (F(1.) - exp_minus2ktau);
+    F rt_term, rt_term2;
+    if constexpr (sizeof(F) == 8)
+    {
+        const F x = fast_rcp(D * fact);
+        rt_term = x * fact;
+        rt_term2 = ssa * x;
+    }
+    else
+    {
+        rt_term = F(1.) / D;
+        rt_term2 = ssa * rt_term / fact;
+    }
     o.r_dif = rt_term * gamma2 * (F(1.) - exp_minus2ktau);
     o.t_dif = rt_term * F(2.) * k * exp_minusktau;
     o.t_noscat = exp(-tau * mu0_inv);
-    const F k_mu = k * mu0;
     const F k_gamma3 = k * gamma3;
     const F k_gamma4 = k * gamma4;
-    const F fact = (abs(F(1.) - k_mu*k_mu) > tmin) ? F(1.) - k_mu*k_mu : tmin;
-    const F rt_term2 = ssa * rt_term / fact;
-    F r_dir = rt_term2 * ((F(1.) - k_mu) * (alpha2 + k_gamma3) -
-                          (F(1.) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
-                          F(2.) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * o.t_noscat);
-    F t_dir = -rt_term2 * ((F(1.) + k_mu) * (alpha1 + k_gamma4) * o.t_noscat -
-                           (F(1.) - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * o.t_noscat -
-                           F(2.) * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+    const F r_dir = rt_term2 * ((F(1.) - k_mu) * (alpha2 + k_gamma3) -
+                                (F(1.) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
+                                F(2.) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * o.t_noscat);
+    const F t_dir = -rt_term2 * ((F(1.) + k_mu) * (alpha1 + k_gamma4) * o.t_noscat -
+                                 (F(1.) - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * o.t_noscat -
+                                 F(2.) * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
     o.r_dir = max(tmin, min(r_dir, F(1.) - o.t_noscat));
     o.t_dir = max(tmin, min(t_dir, F(1.) - o.t_noscat - o.r_dir));
     return o;
@@ -63,28 +83,33 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 
 
 template<typename F, int V, int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
         const F* __restrict__ sfc_alb_dir, const F* __restrict__ sfc_alb_dif,
         const F* __restrict__ inc_flux_dir, const F* __restrict__ inc_flux_dif,
-        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir)
+        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir, const int sync_waves)
 {
+    // per-thread private LDS columns (dynamic register indexing is not needed: j is a compile-time constant, but
+    // two of the six per-layer arrays live here so that the kernel fits 2 waves per SIMD)
+    __shared__ F lds_alb[K*V][256];
+    __shared__ F lds_dir[K*V][256];
+
+    const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
     const int igpt = blockIdx.y;
     const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip)
+    if (sync_waves) __syncthreads();
     if (wave_col0 >= ncol) return;
 
     int icol = wave_col0 + cl*V;
-    int nvalid = ncol - icol;
-    const bool active = nvalid > 0;
-    if (!active) { icol = wave_col0; nvalid = 1; }
-    if (nvalid > V) nvalid = V;
-    const int nld = active ? nvalid : 1;
+    const bool active = icol < ncol;
+    if (!active) icol = wave_col0;
 
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
@@ -93,15 +118,16 @@ sw_2stream_scan_kernel(
     const size_t sfc_idx = size_t(igpt)*ncl + icol;
     const int t0 = ll*K;
 
-    const Vec<F,V> mu = load_cols<F,V>(mu0 + icol, nld);
+    const Vec<F,V> mu = load_cols<F,V>(mu0 + icol);
+    F mu_inv[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v) mu_inv[v] = F(1.)/mu.v[v];
 
-    // per-layer state (see header comment); names follow their LAST meaning
+    // per-layer state; names follow their LAST meaning
     F rp[K][V];      // r_dif            -> p = r_dif*denom
     F al[K][V];      // t_dif            -> alpha = t_dif*denom
     F sb[K][V];      // source_up        -> beta -> src at level t0+j
     F qb[K][V];      // source_dn        -> q = source_dn*denom -> b
-    F alb[K][V];     // albedo at level t0+j
-    F dirv[K][V];    // direct beam at level t0+j
 
     F Tloc[V];
     #pragma unroll
@@ -111,18 +137,20 @@ sw_2stream_scan_kernel(
     #pragma unroll
     for (int j=0; j<K; ++j)
     {
+        // keep at most LOADG layers of loads in flight per wave: the whole burst (3*K loads) would pin 6*K VGPRs
+        if (j % LOADG == 0) __builtin_amdgcn_sched_barrier(0);
         const int s = t0 + j;
         const bool valid = s < nlay;
         const int sc = min(s, nlay-1);
         const int ml = top_at_1 ? sc : nlay-1-sc;
-        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl, nld);
-        const Vec<F,V> wv = load_cols<F,V>(ssa + lay_base + size_t(ml)*ncl, nld);
-        const Vec<F,V> gv = load_cols<F,V>(g   + lay_base + size_t(ml)*ncl, nld);
+        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl);
+        const Vec<F,V> wv = load_cols<F,V>(ssa + lay_base + size_t(ml)*ncl);
+        const Vec<F,V> gv = load_cols<F,V>(g   + lay_base + size_t(ml)*ncl);
         #pragma unroll
         for (int v=0; v<V; ++v)
         {
-            const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v]);
-            dirv[j][v] = Tloc[v];
+            const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
+            lds_dir[j*V+v][tid] = Tloc[v];
             rp[j][v] = valid ? ts.r_dif : F(0.);
             al[j][v] = valid ? ts.t_dif : F(1.);
             sb[j][v] = valid ? ts.r_dir * Tloc[v] : F(0.);
@@ -131,13 +159,13 @@ sw_2stream_scan_kernel(
         }
     }
 
-    const Vec<F,V> inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx, nld);
-    const Vec<F,V> a_dir = load_cols<F,V>(sfc_alb_dir + sfc_idx, nld);
-    const Vec<F,V> a_dif = load_cols<F,V>(sfc_alb_dif + sfc_idx, nld);
+    const Vec<F,V> inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx);
+    const Vec<F,V> a_dir = load_cols<F,V>(sfc_alb_dir + sfc_idx);
+    const Vec<F,V> a_dif = load_cols<F,V>(sfc_alb_dif + sfc_idx);
     Vec<F,V> inc_dif;
-    if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx, nld);
+    if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx);
 
-    Vec<F,V> oup[K], odn[K];
+    F dn_in[V], dir_in[V];
 
     #pragma unroll
     for (int v=0; v<V; ++v)
@@ -153,14 +181,13 @@ sw_2stream_scan_kernel(
         F pe = shfl(pr, lane - CL);
         if (ll == 0) pe = F(1.);
         const F dir_top = inc_dir.v[v] * mu.v[v];
-        const F dir_in = dir_top * pe;
+        dir_in[v] = dir_top * pe;
         const F dir_sfc = shfl(dir_top * pr, (LL-1)*CL + cl);
         #pragma unroll
         for (int j=0; j<K; ++j)
         {
-            dirv[j][v] *= dir_in;
-            sb[j][v] *= dir_in;
-            qb[j][v] *= dir_in;
+            sb[j][v] *= dir_in[v];
+            qb[j][v] *= dir_in[v];
         }
 
         // ---- albedo: Moebius composite of this lane's layers (layer K-1 applied first), normalised to m11 = 1
@@ -175,7 +202,7 @@ sw_2stream_scan_kernel(
             m00 = n00; m01 = n01; m10 = n10; m11 = n11;
         }
         {
-            const F inv = F(1.)/m11;
+            const F inv = fast_rcp(m11);
             m00 *= inv; m01 *= inv; m10 *= inv; m11 = F(1.);
         }
         // inclusive suffix scan: S(ll) = M_ll * M_{ll+1} * ... * M_7
@@ -188,14 +215,14 @@ sw_2stream_scan_kernel(
             {
                 const F n00 = m00*p00 + m01*p10, n01 = m00*p01 + m01;
                 const F n10 = m10*p00 + p10,     n11 = m10*p01 + F(1.);
-                const F inv = F(1.)/n11;
+                const F inv = fast_rcp(n11);
                 m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
             }
         }
         F e00 = shfl(m00, lane + CL), e01 = shfl(m01, lane + CL), e10 = shfl(m10, lane + CL);
         if (ll == LL-1) { e00 = F(1.); e01 = F(0.); e10 = F(0.); }
         const F alb_sfc = a_dif.v[v];
-        F a = (e00*alb_sfc + e01) / (e10*alb_sfc + F(1.));      // albedo at the bottom of this lane's chunk
+        F a = (e00*alb_sfc + e01) * fast_rcp(e10*alb_sfc + F(1.));      // albedo at the bottom of this lane's chunk
 
         // ---- replay albedo upward; build alpha, beta, p, q and the lane's affine composites
         F As = F(1.), Bs = F(0.), Bd = F(0.);    // As: product of alpha (shared); Bs: source (upward); Bd: down
@@ -203,11 +230,11 @@ sw_2stream_scan_kernel(
         for (int j=K-1; j>=0; --j)
         {
             const F r = rp[j][v], t = al[j][v];
-            const F denom = F(1.)/(F(1.) - r*a);
+            const F denom = fast_rcp(F(1.) - r*a);
             const F alpha = t*denom;
             const F beta = sb[j][v] + alpha*a*qb[j][v];
             a = r + t*alpha*a;
-            alb[j][v] = a;
+            lds_alb[j*V+v][tid] = a;
             al[j][v] = alpha;
             sb[j][v] = beta;
             rp[j][v] = r*denom;
@@ -253,33 +280,36 @@ sw_2stream_scan_kernel(
         ae = shfl(da, lane - CL); be = shfl(db, lane - CL);
         if (ll == 0) { ae = F(1.); be = F(0.); }
         const F dn_top = (inc_flux_dif != nullptr) ? inc_dif.v[v] : F(0.);
-        F dn = ae*dn_top + be;
-
-        #pragma unroll
-        for (int j=0; j<K; ++j)
-        {
-            oup[j].v[v] = dn*alb[j][v] + sb[j][v];
-            odn[j].v[v] = dn + dirv[j][v];
-            dn = al[j][v]*dn + qb[j][v];
-        }
+        dn_in[v] = ae*dn_top + be;
     }
 
     if (!active) return;
 
+    // ---- replay the diffuse downward flux and store this lane's K levels as soon as each value exists
+    F dn[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v) dn[v] = dn_in[v];
     #pragma unroll
     for (int j=0; j<K; ++j)
     {
+        Vec<F,V> ou, od, odr;
+        #pragma unroll
+        for (int v=0; v<V; ++v)
+        {
+            const F dr = dir_in[v] * lds_dir[j*V+v][tid];
+            ou.v[v] = dn[v]*lds_alb[j*V+v][tid] + sb[j][v];
+            od.v[v] = dn[v] + dr;
+            odr.v[v] = dr;
+            dn[v] = al[j][v]*dn[v] + qb[j][v];
+        }
         const int t = t0 + j;
         if (t <= nlay)
         {
             const int ml = top_at_1 ? t : nlay - t;
             const size_t o = lev_base + size_t(ml)*ncl;
-            Vec<F,V> od;
-            #pragma unroll
-            for (int v=0; v<V; ++v) od.v[v] = dirv[j][v];
-            store_cols<F,V>(flux_up + o, oup[j], nvalid);
-            store_cols<F,V>(flux_dn + o, odn[j], nvalid);
-            store_cols<F,V>(flux_dir + o, od, nvalid);
+            store_cols<F,V>(flux_up + o, ou);
+            store_cols<F,V>(flux_dn + o, od);
+            store_cols<F,V>(flux_dir + o, odr);
         }
     }
 }
@@ -318,7 +348,7 @@ sw_2stream_serial_kernel(
     for (int s=0; s<nlay; ++s)
     {
         const size_t il = mlay(s);
-        const TwoStream<F> ts = two_stream<F>(tau[il], ssa[il], g[il], mu);
+        const TwoStream<F> ts = two_stream<F>(tau[il], ssa[il], g[il], mu, F(1.)/mu);
         w_r[il] = ts.r_dif; w_t[il] = ts.t_dif;
         w_su[il] = ts.r_dir * dir; w_sd[il] = ts.t_dir * dir;
         flux_dir[mlev(s)] = dir;
@@ -379,6 +409,9 @@ __global__ void apply_BC_kernel(const int ncol, const int nlay, const int ngpt, 
 }
 
 int g_sw_variant = 0;   // 0 = auto (scan), 1 = force serial
+int g_sync_waves = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
+
+extern int g_sync_waves;
 
 template<typename F, int V>
 bool launch_scan(hipStream_t st,
@@ -390,7 +423,7 @@ bool launch_scan(hipStream_t st,
     const int need = ceil_div(nlay+1, LL);
 #define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK><<<grid, 256, 0, st>>>( \
         ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-        flux_up, flux_dn, flux_dir); return true; }
+        flux_up, flux_dn, flux_dir, g_sync_waves); return true; }
     RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33)
 #undef RRX_SW_K
     return false;
@@ -424,8 +457,17 @@ int sw_solver_2stream_impl(
 
     bool done = false;
     if (g_sw_variant != 1)
-        done = launch_scan<F,1>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                inc_flux_dir, dif, up, dn, dr);
+    {
+        if constexpr (sizeof(F) == 4)
+        {
+            if (ncol % 2 == 0)
+                done = launch_scan<F,2>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                    inc_flux_dir, dif, up, dn, dr);
+        }
+        if (!done)
+            done = launch_scan<F,1>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                    inc_flux_dir, dif, up, dn, dr);
+    }
     if (!done)
     {
         F* ws2 = nullptr;
