@@ -44,6 +44,10 @@ int rrx_memset(void* dst, int value, unsigned long long bytes, void* stream);
 int rrx_synchronize(void* stream);
 int rrx_stream_create(void** stream);
 int rrx_stream_destroy(void* stream);
+/* include/Array.h:311-350,579-622 (Array_gpu::subset / subset_kernel): N-D block gather, singleton dimensions are
+   broadcast. sub_dims/strides/starts/spread are HOST arrays of length ndim (<= 7); strides in elements, starts 0-based. */
+int rrx_subset_nd(void* out, const void* in, int elem_bytes, int ndim, const int* sub_dims, const long long* strides,
+                  const int* starts, const int* spread, void* stream);
 /* kernel-variant switches used by bench.py A/B runs (0 = default) */
 int rrx_set_lw_variant(int v);
 int rrx_set_sw_variant(int v);

@@ -278,6 +278,24 @@ __global__ void subset_cols_kernel(const int ncol_full, const size_t nrest, cons
     }
 }
 
+// Generic N-D block gather with broadcast of singleton dimensions: include/Array.h:311-350,579-622 of the reference.
+struct SubsetND { int ndim; int sub_dims[7]; long long strides[7]; int starts[7]; int spread[7]; };
+
+template<typename T>
+__global__ void subset_nd_kernel(const SubsetND sd, const size_t n, const T* __restrict__ in, T* __restrict__ out)
+{
+    RRX_GRID_STRIDE(i, n)
+    {
+        size_t rem = i; long long src = 0;
+        for (int d=0; d<sd.ndim; ++d)
+        {
+            const int id = int(rem % sd.sub_dims[d]); rem /= sd.sub_dims[d];
+            src += (sd.spread[d] ? 0 : (long long)(id + sd.starts[d])) * sd.strides[d];
+        }
+        out[i] = in[src];
+    }
+}
+
 template<typename F>
 __global__ void fill_kernel(const size_t n, const F v, F* __restrict__ a)
 {
@@ -306,6 +324,21 @@ int rrx_stream_create(void** stream) { hipStream_t s; RRX_HIP_OK(hipStreamCreate
 int rrx_stream_destroy(void* stream) { RRX_HIP_OK(hipStreamDestroy(static_cast<hipStream_t>(stream)), "rrx_stream_destroy"); return 0; }
 
 #define ST static_cast<hipStream_t>(stream)
+
+int rrx_subset_nd(void* out, const void* in, int elem_bytes, int ndim, const int* sub_dims, const long long* strides,
+                  const int* starts, const int* spread, void* stream)
+{
+    RRX_TRY
+    if (ndim < 1 || ndim > 7) throw std::runtime_error("ndim must be 1..7");
+    SubsetND sd; sd.ndim = ndim; size_t n = 1;
+    for (int d=0; d<ndim; ++d) { sd.sub_dims[d] = sub_dims[d]; sd.strides[d] = strides[d]; sd.starts[d] = starts[d]; sd.spread[d] = spread[d]; n *= sub_dims[d]; }
+    if (n == 0) return 0;
+    if (elem_bytes == 8) subset_nd_kernel<double><<<grid1d(n), 256, 0, ST>>>(sd, n, static_cast<const double*>(in), static_cast<double*>(out));
+    else if (elem_bytes == 4) subset_nd_kernel<int><<<grid1d(n), 256, 0, ST>>>(sd, n, static_cast<const int*>(in), static_cast<int*>(out));
+    else if (elem_bytes == 1) subset_nd_kernel<signed char><<<grid1d(n), 256, 0, ST>>>(sd, n, static_cast<const signed char*>(in), static_cast<signed char*>(out));
+    else throw std::runtime_error("element size must be 1, 4 or 8 bytes");
+    RRX_CATCH("rrx_subset_nd")
+}
 
 #define RRX_DEFINE_MISC(F, SFX) \
 int rrx_increment_1scalar_by_1scalar##SFX(int ncol, int nlay, int ngpt, F* tau_inout, const F* tau_in, void* stream) \

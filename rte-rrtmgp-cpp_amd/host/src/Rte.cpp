@@ -1,0 +1,108 @@
+// Rte_lw_gpu / Rte_sw_gpu: /root/reference/src_cuda/Rte_lw.cu:60-159 and src_cuda/Rte_sw.cu:116-185.
+#include "Rte_lw.h"
+#include "Rte_sw.h"
+#include "rte_solver_kernels_cuda.h"
+
+namespace
+{
+    // Gauss-Jacobi-5 quadrature, Table 1 of R. J. Hogan 2023, doi:10.1002/qj.4598 (as in src/Rte_lw.cpp:140-152)
+    constexpr int max_gauss_pts = 4;
+    const std::vector<Float> gauss_Ds_v = {
+        1./0.6096748751, 0.            , 0.             , 0.,
+        1./0.2509907356, 1/0.7908473988, 0.             , 0.,
+        1./0.1024922169, 1/0.4417960320, 1./0.8633751621, 0.,
+        1./0.0454586727, 1/0.2322334416, 1./0.5740198775, 1./0.903077597 };
+    const std::vector<Float> gauss_wts_v = {
+        1.,           0.,           0.,           0.,
+        0.2300253764, 0.7699746236, 0.,           0.,
+        0.0437820218, 0.3875796738, 0.5686383044, 0.,
+        0.0092068785, 0.1285704278, 0.4323381850, 0.4298845087 };
+
+    void expand(const std::unique_ptr<Optical_props_arry_gpu>& ops, const Array_gpu<Float,2>& arr_in, Array_gpu<Float,2>& arr_out)
+    {
+        RRX_CALL(rrx_expand_and_transpose, arr_in.dim(2), ops->get_nband(), ops->get_band_lims_gpoint_gpu().ptr(), arr_in.ptr(), arr_out.ptr());
+    }
+}
+
+void Rte_lw_gpu::rte_lw(
+        const std::unique_ptr<Optical_props_arry_gpu>& optical_props,
+        const Bool top_at_1,
+        const Source_func_lw_gpu& sources,
+        const Array_gpu<Float,2>& sfc_emis,
+        const Array_gpu<Float,2>& inc_flux,
+        Array_gpu<Float,3>& gpt_flux_up,
+        Array_gpu<Float,3>& gpt_flux_dn,
+        const int n_gauss_angles)
+{
+    if (n_gauss_angles < 1 || n_gauss_angles > max_gauss_pts) throw std::runtime_error("rte_lw: n_gauss_angles must be 1..4");
+    const int ncol = optical_props->get_ncol();
+    const int nlay = optical_props->get_nlay();
+    const int ngpt = optical_props->get_ngpt();
+
+    Array_gpu<Float,2> sfc_emis_gpt({ncol, ngpt});
+    expand_and_transpose(optical_props, sfc_emis, sfc_emis_gpt);
+
+    const Array_gpu<Float,2> gauss_Ds(Array<Float,2>(gauss_Ds_v, {max_gauss_pts, max_gauss_pts}));
+    const Array<Float,2> gauss_wts(gauss_wts_v, {max_gauss_pts, max_gauss_pts});
+    const Array_gpu<Float,2> gauss_wts_subset(gauss_wts.subset({{ {1, n_gauss_angles}, {n_gauss_angles, n_gauss_angles} }}));
+
+    Array_gpu<Float,3> secants({ncol, ngpt, n_gauss_angles});
+    Rte_solver_kernels_cuda::lw_secants_array(ncol, ngpt, n_gauss_angles, max_gauss_pts, gauss_Ds.ptr(), secants.ptr());
+
+    const Bool do_broadband = (gpt_flux_up.dim(3) == 1 && ngpt != 1);
+    const Bool do_jacobians = false;
+    const Float* inc_flux_ptr = (inc_flux.size() == 0) ? nullptr : inc_flux.ptr();
+
+    Rte_solver_kernels_cuda::lw_solver_noscat(
+            ncol, nlay, ngpt, top_at_1, n_gauss_angles,
+            secants.ptr(), gauss_wts_subset.ptr(),
+            optical_props->get_tau().ptr(),
+            sources.get_lay_source().ptr(), sources.get_lev_source().ptr(),
+            sfc_emis_gpt.ptr(), sources.get_sfc_source().ptr(),
+            inc_flux_ptr,
+            gpt_flux_up.ptr(), gpt_flux_dn.ptr(),
+            do_broadband, gpt_flux_up.ptr(), gpt_flux_dn.ptr(),
+            do_jacobians, nullptr, nullptr);
+}
+
+void Rte_lw_gpu::expand_and_transpose(const std::unique_ptr<Optical_props_arry_gpu>& ops, const Array_gpu<Float,2> arr_in, Array_gpu<Float,2>& arr_out)
+{ expand(ops, arr_in, arr_out); }
+
+void Rte_sw_gpu::rte_sw(
+        const std::unique_ptr<Optical_props_arry_gpu>& optical_props,
+        const Bool top_at_1,
+        const Array_gpu<Float,1>& mu0,
+        const Array_gpu<Float,2>& inc_flux_dir,
+        const Array_gpu<Float,2>& sfc_alb_dir,
+        const Array_gpu<Float,2>& sfc_alb_dif,
+        const Array_gpu<Float,2>& inc_flux_dif,
+        Array_gpu<Float,3>& gpt_flux_up,
+        Array_gpu<Float,3>& gpt_flux_dn,
+        Array_gpu<Float,3>& gpt_flux_dir)
+{
+    const int ncol = optical_props->get_ncol();
+    const int nlay = optical_props->get_nlay();
+    const int ngpt = optical_props->get_ngpt();
+
+    Array_gpu<Float,2> sfc_alb_dir_gpt({ncol, ngpt});
+    Array_gpu<Float,2> sfc_alb_dif_gpt({ncol, ngpt});
+    expand_and_transpose(optical_props, sfc_alb_dir, sfc_alb_dir_gpt);
+    expand_and_transpose(optical_props, sfc_alb_dif, sfc_alb_dif_gpt);
+
+    const Bool has_dif_bc = (inc_flux_dif.size() > 0);
+    const Bool do_broadband = (gpt_flux_up.dim(3) == 1 && ngpt != 1);
+    const Float* inc_flux_dif_ptr = has_dif_bc ? inc_flux_dif.ptr() : nullptr;
+
+    Rte_solver_kernels_cuda::sw_solver_2stream(
+            ncol, nlay, ngpt, top_at_1,
+            optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), optical_props->get_g().ptr(),
+            mu0.ptr(),
+            sfc_alb_dir_gpt.ptr(), sfc_alb_dif_gpt.ptr(),
+            inc_flux_dir.ptr(),
+            gpt_flux_up.ptr(), gpt_flux_dn.ptr(), gpt_flux_dir.ptr(),
+            has_dif_bc, inc_flux_dif_ptr,
+            do_broadband, gpt_flux_up.ptr(), gpt_flux_dn.ptr(), gpt_flux_dir.ptr());
+}
+
+void Rte_sw_gpu::expand_and_transpose(const std::unique_ptr<Optical_props_arry_gpu>& ops, const Array_gpu<Float,2> arr_in, Array_gpu<Float,2>& arr_out)
+{ expand(ops, arr_in, arr_out); }

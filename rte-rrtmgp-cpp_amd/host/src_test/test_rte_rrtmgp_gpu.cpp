@@ -1,0 +1,365 @@
+// test_rte_rrtmgp_gpu -- stand-alone driver with the command line, file names, variable names and flow of the reference's
+// /root/reference/src_test/test_rte_rrtmgp.cu:196-818: read rte_rrtmgp_input, build the solvers from
+// coefficients_{lw,sw} (+ cloud_coefficients_*), upload, solve on the GPU (1 warm-up + 1 timed run, 10 more with
+// --timings), download, write rte_rrtmgp_output. Files are RRXB containers (include_test/Netcdf_interface.h), extension .nc
+// kept so that run scripts need no change; two extra options: --broadband-solvers (never materialise per-g-point
+// fluxes) and the environment variable RRX_COL_BLOCK (columns per block, default 16384).
+#include <chrono>
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+#include "Status.h"
+#include "Netcdf_interface.h"
+#include "Array.h"
+#include "Gas_concs.h"
+#include "Radiation_solver.h"
+
+namespace
+{
+    void read_and_set_vmr(const std::string& gas_name, const int n_col_x, const int n_col_y, const int n_lay,
+                          const Netcdf_handle& input_nc, Gas_concs& gas_concs)
+    {
+        const std::string vmr_gas_name = "vmr_" + gas_name;
+        if (!input_nc.variable_exists(vmr_gas_name))
+        {
+            Status::print_warning("Gas \"" + gas_name + "\" not available in input file.");
+            return;
+        }
+        const std::map<std::string, int> dims = input_nc.get_variable_dimensions(vmr_gas_name);
+        const int n_dims = int(dims.size());
+        if (n_dims == 0)
+            gas_concs.set_vmr(gas_name, input_nc.get_variable<Float>(vmr_gas_name));
+        else if (n_dims == 1)
+        {
+            if (dims.count("lay") == 0) throw std::runtime_error("Illegal dimensions of gas \"" + gas_name + "\" in input");
+            gas_concs.set_vmr(gas_name, Array<Float,1>(input_nc.get_variable<Float>(vmr_gas_name, {n_lay}), {n_lay}));
+        }
+        else if (n_dims == 3)
+            gas_concs.set_vmr(gas_name, Array<Float,2>(input_nc.get_variable<Float>(vmr_gas_name, {n_lay, n_col_y, n_col_x}), {n_col_x*n_col_y, n_lay}));
+        else
+            throw std::runtime_error("Illegal dimensions of gas \"" + gas_name + "\" in input");
+    }
+
+    bool parse_command_line_options(std::map<std::string, std::pair<bool, std::string>>& options, int argc, char** argv)
+    {
+        for (int i=1; i<argc; ++i)
+        {
+            std::string argument(argv[i]);
+            if (argument == "-h" || argument == "--help")
+            {
+                Status::print_message("Possible usage:");
+                for (const auto& clo : options)
+                {
+                    std::ostringstream ss;
+                    ss << std::left << std::setw(30) << ("--" + clo.first) << clo.second.second;
+                    Status::print_message(ss.str());
+                }
+                return true;
+            }
+            if (argument.size() < 3 || argument[0] != '-' || argument[1] != '-')
+                throw std::runtime_error(argument + " is an illegal command line option.");
+            argument.erase(0, 2);
+            bool enable = true;
+            if (argument.compare(0, 3, "no-") == 0) { enable = false; argument.erase(0, 3); }
+            if (options.find(argument) == options.end())
+                throw std::runtime_error(argument + " is an illegal command line option.");
+            options.at(argument).first = enable;
+        }
+        return false;
+    }
+
+    double now_ms()
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+}
+
+
+void solve_radiation(int argc, char** argv)
+{
+    Status::print_message("###### Starting RTE+RRTMGP solver ######");
+
+    std::map<std::string, std::pair<bool, std::string>> command_line_options {
+        {"shortwave"        , { true,  "Enable computation of shortwave radiation."}},
+        {"longwave"         , { true,  "Enable computation of longwave radiation." }},
+        {"fluxes"           , { true,  "Enable computation of fluxes."             }},
+        {"cloud-optics"     , { false, "Enable cloud optics."                      }},
+        {"aerosol-optics"   , { false, "Enable aerosol optics (not available in this build)." }},
+        {"output-optical"   , { false, "Enable output of optical properties."      }},
+        {"output-bnd-fluxes", { false, "Enable output of band fluxes."             }},
+        {"timings"          , { false, "Repeat computation 10x for run times."     }},
+        {"delta-cloud"      , { true,  "delta-scaling of cloud optical properties"   }},
+        {"delta-aerosol"    , { false, "delta-scaling of aerosol optical properties" }},
+        {"broadband-solvers", { false, "Sum g-points inside the solvers (no per-g-point fluxes)." }}};
+
+    if (parse_command_line_options(command_line_options, argc, argv))
+        return;
+
+    const bool switch_shortwave         = command_line_options.at("shortwave"        ).first;
+    const bool switch_longwave          = command_line_options.at("longwave"         ).first;
+    const bool switch_fluxes            = command_line_options.at("fluxes"           ).first;
+    const bool switch_cloud_optics      = command_line_options.at("cloud-optics"     ).first;
+    const bool switch_aerosol_optics    = command_line_options.at("aerosol-optics"   ).first;
+    const bool switch_output_optical    = command_line_options.at("output-optical"   ).first;
+    const bool switch_output_bnd_fluxes = command_line_options.at("output-bnd-fluxes").first;
+    const bool switch_timings           = command_line_options.at("timings"          ).first;
+    const bool switch_delta_cloud       = command_line_options.at("delta-cloud"      ).first;
+    const bool switch_delta_aerosol     = command_line_options.at("delta-aerosol"    ).first;
+    const bool switch_broadband         = command_line_options.at("broadband-solvers").first;
+
+    Status::print_message("Solver settings:");
+    for (const auto& option : command_line_options)
+    {
+        std::ostringstream ss;
+        ss << std::left << std::setw(20) << option.first << " = " << std::boolalpha << option.second.first;
+        Status::print_message(ss.str());
+    }
+    const int col_block = std::getenv("RRX_COL_BLOCK") ? std::atoi(std::getenv("RRX_COL_BLOCK")) : 16384;
+
+    ////// READ THE ATMOSPHERIC DATA //////
+    Status::print_message("Reading atmospheric input data from NetCDF.");
+    Netcdf_file input_nc("rte_rrtmgp_input.nc", Netcdf_mode::Read);
+    const int n_col_x = input_nc.get_dimension_size("x");
+    const int n_col_y = input_nc.get_dimension_size("y");
+    const int n_col = n_col_x * n_col_y;
+    const int n_lay = input_nc.get_dimension_size("lay");
+    const int n_lev = input_nc.get_dimension_size("lev");
+
+    Array<Float,2> p_lay(input_nc.get_variable<Float>("p_lay", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+    Array<Float,2> t_lay(input_nc.get_variable<Float>("t_lay", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+    Array<Float,2> p_lev(input_nc.get_variable<Float>("p_lev", {n_lev, n_col_y, n_col_x}), {n_col, n_lev});
+    Array<Float,2> t_lev(input_nc.get_variable<Float>("t_lev", {n_lev, n_col_y, n_col_x}), {n_col, n_lev});
+
+    Array<Float,2> col_dry;
+    if (input_nc.variable_exists("col_dry"))
+        col_dry = Array<Float,2>(input_nc.get_variable<Float>("col_dry", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+
+    Gas_concs gas_concs;
+    for (const char* gas : {"h2o", "co2", "o3", "n2o", "co", "ch4", "o2", "n2", "ccl4", "cfc11", "cfc12", "cfc22",
+                            "hfc143a", "hfc125", "hfc23", "hfc32", "hfc134a", "cf4", "no2"})
+        read_and_set_vmr(gas, n_col_x, n_col_y, n_lay, input_nc, gas_concs);
+
+    Array<Float,2> lwp, iwp, rel, dei;
+    if (switch_cloud_optics)
+    {
+        lwp = Array<Float,2>(input_nc.get_variable<Float>("lwp", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+        iwp = Array<Float,2>(input_nc.get_variable<Float>("iwp", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+        rel = Array<Float,2>(input_nc.get_variable<Float>("rel", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+        dei = Array<Float,2>(input_nc.get_variable<Float>("dei", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+    }
+
+    ////// CREATE THE OUTPUT FILE //////
+    Status::print_message("Preparing NetCDF output file.");
+    Netcdf_file output_nc("rte_rrtmgp_output.nc", Netcdf_mode::Create);
+    output_nc.add_dimension("x", n_col_x);
+    output_nc.add_dimension("y", n_col_y);
+    output_nc.add_dimension("lay", n_lay);
+    output_nc.add_dimension("lev", n_lev);
+    output_nc.add_dimension("pair", 2);
+    output_nc.add_variable<Float>("p_lay", {"lay", "y", "x"}).insert(p_lay.v(), {0, 0, 0});
+    output_nc.add_variable<Float>("p_lev", {"lev", "y", "x"}).insert(p_lev.v(), {0, 0, 0});
+
+    Gas_concs_gpu gas_concs_gpu(gas_concs);
+    Array_gpu<Float,2> p_lay_gpu(p_lay), p_lev_gpu(p_lev), t_lay_gpu(t_lay), t_lev_gpu(t_lev), col_dry_gpu(col_dry);
+    Array_gpu<Float,2> lwp_gpu(lwp), iwp_gpu(iwp), rel_gpu(rel), dei_gpu(dei);
+
+    auto time_runs = [&](const std::string& name, const std::function<void()>& run)
+    {
+        run();                                               // warm-up (allocations, first launches)
+        rrx_host::check(rrx_synchronize(nullptr));
+        const int n_runs = switch_timings ? 11 : 1;
+        for (int i=0; i<n_runs; ++i)
+        {
+            const double t0 = now_ms();
+            run();
+            rrx_host::check(rrx_synchronize(nullptr));
+            Status::print_message("Duration " + name + " solver: " + std::to_string(now_ms() - t0) + " (ms)");
+        }
+    };
+
+    ////// RUN THE LONGWAVE SOLVER //////
+    if (switch_longwave)
+    {
+        Status::print_message("Initializing the longwave solver.");
+        Radiation_solver_longwave rad_lw(gas_concs_gpu, "coefficients_lw.nc", switch_cloud_optics ? "cloud_coefficients_lw.nc" : "");
+        rad_lw.set_column_block(col_block);
+        rad_lw.set_broadband_solvers(switch_broadband);
+
+        const int n_bnd_lw = rad_lw.get_n_bnd_gpu();
+        const int n_gpt_lw = rad_lw.get_n_gpt_gpu();
+        Array<Float,2> emis_sfc(input_nc.get_variable<Float>("emis_sfc", {n_col_y, n_col_x, n_bnd_lw}), {n_bnd_lw, n_col});
+        Array<Float,1> t_sfc(input_nc.get_variable<Float>("t_sfc", {n_col_y, n_col_x}), {n_col});
+        Array_gpu<Float,2> emis_sfc_gpu(emis_sfc);
+        Array_gpu<Float,1> t_sfc_gpu(t_sfc);
+
+        Array_gpu<Float,3> lw_tau, lay_source, lev_source;
+        Array_gpu<Float,2> sfc_source;
+        if (switch_output_optical)
+        {
+            lw_tau.set_dims({n_col, n_lay, n_gpt_lw}); lay_source.set_dims({n_col, n_lay, n_gpt_lw});
+            lev_source.set_dims({n_col, n_lev, n_gpt_lw}); sfc_source.set_dims({n_col, n_gpt_lw});
+        }
+        Array_gpu<Float,2> lw_flux_up, lw_flux_dn, lw_flux_net;
+        if (switch_fluxes) { lw_flux_up.set_dims({n_col, n_lev}); lw_flux_dn.set_dims({n_col, n_lev}); lw_flux_net.set_dims({n_col, n_lev}); }
+        Array_gpu<Float,3> lw_bnd_flux_up, lw_bnd_flux_dn, lw_bnd_flux_net;
+        if (switch_output_bnd_fluxes)
+        {
+            lw_bnd_flux_up.set_dims({n_col, n_lev, n_bnd_lw}); lw_bnd_flux_dn.set_dims({n_col, n_lev, n_bnd_lw}); lw_bnd_flux_net.set_dims({n_col, n_lev, n_bnd_lw});
+        }
+
+        Status::print_message("Solving the longwave radiation.");
+        time_runs("longwave", [&]()
+        {
+            rad_lw.solve_gpu(switch_fluxes, switch_cloud_optics, switch_output_optical, switch_output_bnd_fluxes,
+                    gas_concs_gpu, p_lay_gpu, p_lev_gpu, t_lay_gpu, t_lev_gpu, col_dry_gpu, t_sfc_gpu, emis_sfc_gpu,
+                    lwp_gpu, iwp_gpu, rel_gpu, dei_gpu, lw_tau, lay_source, lev_source, sfc_source,
+                    lw_flux_up, lw_flux_dn, lw_flux_net, lw_bnd_flux_up, lw_bnd_flux_dn, lw_bnd_flux_net);
+        });
+
+        Status::print_message("Storing the longwave output.");
+        output_nc.add_dimension("gpt_lw", n_gpt_lw);
+        output_nc.add_dimension("band_lw", n_bnd_lw);
+        output_nc.add_variable<Float>("lw_band_lims_wvn", {"band_lw", "pair"}).insert(rad_lw.get_band_lims_wavenumber_gpu().v(), {0, 0});
+        if (switch_output_optical)
+        {
+            output_nc.add_variable<int>("lw_band_lims_gpt", {"band_lw", "pair"}).insert(rad_lw.get_band_lims_gpoint_gpu().v(), {0, 0});
+            output_nc.add_variable<Float>("lw_tau", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(lw_tau).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("lay_source", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(lay_source).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("lev_source", {"gpt_lw", "lev", "y", "x"}).insert(Array<Float,3>(lev_source).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("sfc_source", {"gpt_lw", "y", "x"}).insert(Array<Float,2>(sfc_source).v(), {0, 0, 0});
+        }
+        if (switch_fluxes)
+        {
+            output_nc.add_variable<Float>("lw_flux_up" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_up ).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_flux_dn" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_dn ).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_flux_net", {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_net).v(), {0, 0, 0});
+            if (switch_output_bnd_fluxes)
+            {
+                output_nc.add_variable<Float>("lw_bnd_flux_up" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_up ).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("lw_bnd_flux_dn" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_dn ).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("lw_bnd_flux_net", {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_net).v(), {0, 0, 0, 0});
+            }
+        }
+    }
+
+    ////// RUN THE SHORTWAVE SOLVER //////
+    if (switch_shortwave)
+    {
+        Status::print_message("Initializing the shortwave solver.");
+        Radiation_solver_shortwave rad_sw(gas_concs_gpu, switch_cloud_optics, switch_aerosol_optics,
+                "coefficients_sw.nc", "cloud_coefficients_sw.nc", "aerosol_optics.nc");
+        rad_sw.set_column_block(col_block);
+        rad_sw.set_broadband_solvers(switch_broadband);
+
+        const int n_bnd_sw = rad_sw.get_n_bnd_gpu();
+        const int n_gpt_sw = rad_sw.get_n_gpt_gpu();
+        Array<Float,1> mu0(input_nc.get_variable<Float>("mu0", {n_col_y, n_col_x}), {n_col});
+        Array<Float,2> sfc_alb_dir(input_nc.get_variable<Float>("sfc_alb_dir", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col});
+        Array<Float,2> sfc_alb_dif(input_nc.get_variable<Float>("sfc_alb_dif", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col});
+
+        Array<Float,1> tsi_scaling({n_col});
+        if (input_nc.variable_exists("tsi"))
+        {
+            Array<Float,1> tsi(input_nc.get_variable<Float>("tsi", {n_col_y, n_col_x}), {n_col});
+            const Float tsi_ref = rad_sw.get_tsi_gpu();
+            for (int icol=1; icol<=n_col; ++icol) tsi_scaling({icol}) = tsi({icol}) / tsi_ref;
+        }
+        else if (input_nc.variable_exists("tsi_scaling"))
+        {
+            const Float tsi_scaling_in = input_nc.get_variable<Float>("tsi_scaling");
+            for (int icol=1; icol<=n_col; ++icol) tsi_scaling({icol}) = tsi_scaling_in;
+        }
+        else
+            for (int icol=1; icol<=n_col; ++icol) tsi_scaling({icol}) = Float(1.);
+
+        Array_gpu<Float,1> mu0_gpu(mu0), tsi_scaling_gpu(tsi_scaling);
+        Array_gpu<Float,2> sfc_alb_dir_gpu(sfc_alb_dir), sfc_alb_dif_gpu(sfc_alb_dif), rh_gpu;
+        Aerosol_concs_gpu aerosol_concs_gpu;
+
+        Array_gpu<Float,3> sw_tau, ssa, g;
+        Array_gpu<Float,2> toa_src;
+        if (switch_output_optical)
+        {
+            sw_tau.set_dims({n_col, n_lay, n_gpt_sw}); ssa.set_dims({n_col, n_lay, n_gpt_sw}); g.set_dims({n_col, n_lay, n_gpt_sw});
+            toa_src.set_dims({n_col, n_gpt_sw});
+        }
+        Array_gpu<Float,2> sw_flux_up, sw_flux_dn, sw_flux_dn_dir, sw_flux_net;
+        if (switch_fluxes)
+        {
+            sw_flux_up.set_dims({n_col, n_lev}); sw_flux_dn.set_dims({n_col, n_lev}); sw_flux_dn_dir.set_dims({n_col, n_lev}); sw_flux_net.set_dims({n_col, n_lev});
+        }
+        Array_gpu<Float,3> sw_bnd_flux_up, sw_bnd_flux_dn, sw_bnd_flux_dn_dir, sw_bnd_flux_net;
+        if (switch_output_bnd_fluxes)
+        {
+            sw_bnd_flux_up.set_dims({n_col, n_lev, n_bnd_sw}); sw_bnd_flux_dn.set_dims({n_col, n_lev, n_bnd_sw});
+            sw_bnd_flux_dn_dir.set_dims({n_col, n_lev, n_bnd_sw}); sw_bnd_flux_net.set_dims({n_col, n_lev, n_bnd_sw});
+        }
+
+        Status::print_message("Solving the shortwave radiation.");
+        time_runs("shortwave", [&]()
+        {
+            rad_sw.solve_gpu(switch_fluxes, switch_cloud_optics, switch_aerosol_optics, switch_output_optical, switch_output_bnd_fluxes,
+                    switch_delta_cloud, switch_delta_aerosol, gas_concs_gpu, p_lay_gpu, p_lev_gpu, t_lay_gpu, t_lev_gpu, col_dry_gpu,
+                    sfc_alb_dir_gpu, sfc_alb_dif_gpu, tsi_scaling_gpu, mu0_gpu, lwp_gpu, iwp_gpu, rel_gpu, dei_gpu, rh_gpu, aerosol_concs_gpu,
+                    sw_tau, ssa, g, toa_src, sw_flux_up, sw_flux_dn, sw_flux_dn_dir, sw_flux_net,
+                    sw_bnd_flux_up, sw_bnd_flux_dn, sw_bnd_flux_dn_dir, sw_bnd_flux_net);
+        });
+
+        Status::print_message("Storing the shortwave output.");
+        output_nc.add_dimension("gpt_sw", n_gpt_sw);
+        output_nc.add_dimension("band_sw", n_bnd_sw);
+        output_nc.add_variable<Float>("sw_band_lims_wvn", {"band_sw", "pair"}).insert(rad_sw.get_band_lims_wavenumber_gpu().v(), {0, 0});
+        if (switch_output_optical)
+        {
+            output_nc.add_variable<int>("sw_band_lims_gpt", {"band_sw", "pair"}).insert(rad_sw.get_band_lims_gpoint_gpu().v(), {0, 0});
+            output_nc.add_variable<Float>("sw_tau", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(sw_tau).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("ssa", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(ssa).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("g", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(g).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("toa_source", {"gpt_sw", "y", "x"}).insert(Array<Float,2>(toa_src).v(), {0, 0, 0});
+        }
+        if (switch_fluxes)
+        {
+            output_nc.add_variable<Float>("sw_flux_up"    , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_up    ).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_dn"    , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn    ).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_dn_dir", {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn_dir).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_net"   , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_net   ).v(), {0, 0, 0});
+            if (switch_output_bnd_fluxes)
+            {
+                output_nc.add_variable<Float>("sw_bnd_flux_up"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_up    ).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_dn"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_dn    ).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_dn_dir", {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_dn_dir).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_net"   , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_net   ).v(), {0, 0, 0, 0});
+            }
+        }
+    }
+    output_nc.sync();
+    Status::print_message("###### Finished RTE+RRTMGP solver ######");
+}
+
+
+// C entry point for tests (ctypes): same behaviour and exit status as main().
+extern "C" int rrx_host_main(int argc, char** argv)
+{
+    try
+    {
+        solve_radiation(argc, argv);
+    }
+    catch (const std::exception& e)
+    {
+        Status::print_error(std::string("EXCEPTION: ") + e.what());
+        return 1;
+    }
+    catch (...)
+    {
+        Status::print_error("UNHANDLED EXCEPTION!");
+        return 1;
+    }
+    return 0;
+}
+
+#ifndef RRX_NO_MAIN
+int main(int argc, char** argv) { return rrx_host_main(argc, argv); }
+#endif

@@ -1,0 +1,106 @@
+"""GPU tests of the C++ host layer (include/*.h class API + Radiation_solver + the test_rte_rrtmgp_gpu driver flow) through
+the C entry point rrx_host_main of librte_rrtmgp_hip.so, on files in the reference's layout (synthetic_files.py).
+The same inputs go through (a) the C++ classes, (b) the Python launcher-level pipeline on the HIP kernels and (c) the CPU
+oracle; (a) exercises Gas_optics_rrtmgp_gpu's constructor reductions (an absent gas and its minor contributors are dropped)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from rte_rrtmgp_cpp_amd import synthetic, synthetic_files, rrxio, pipeline
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTLIB = os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "librte_rrtmgp_hip.so")
+KW = dict(ngpt=48, nbnd=3, npres=12, nflav=4, nminor_lower=7, nminor_upper=4)
+
+
+def run_driver(workdir, *flags, env=None):
+    lib = ctypes.CDLL(HOSTLIB)
+    argv = [b"test_rte_rrtmgp_gpu"] + [f.encode() for f in flags]
+    arr = (ctypes.c_char_p * len(argv))(*argv)
+    old = os.getcwd()
+    saved = {}
+    for k, v in (env or {}).items():
+        saved[k] = os.environ.get(k); os.environ[k] = v
+    try:
+        os.chdir(workdir)
+        rc = lib.rrx_host_main(len(argv), arr)
+    finally:
+        os.chdir(old)
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    return rc
+
+
+@pytest.fixture(scope="module")
+def case(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("rrx_case"))
+    kl, ks = synthetic.make_kdist("lw", **KW), synthetic.make_kdist("sw", **KW)
+    atm = synthetic.make_atmosphere(45, 60, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], clouds=True, seed=5)
+    ll, ls = synthetic.make_cloud_lut(KW["nbnd"], "lw"), synthetic.make_cloud_lut(KW["nbnd"], "sw")
+    synthetic_files.write_case(d, atm, kl, ks, ll, ls)
+    return dict(dir=d, kl=kl, ks=ks, atm=atm, ll=ll, ls=ls)
+
+
+def reference_fluxes(be, case, clouds):
+    kl, ks = be.upload_kdist(case["kl"]), be.upload_kdist(case["ks"])
+    atm = pipeline.upload_atmosphere(be, case["atm"])
+    lw = pipeline.solve_lw(be, kl, atm, cloud_lut=be.upload_lut(case["ll"]) if clouds else None, keep=True)
+    sw = pipeline.solve_sw(be, ks, atm, cloud_lut=be.upload_lut(case["ls"]) if clouds else None, delta_cloud=True, keep=True)
+    N = be.to_numpy
+    return dict(lw_flux_up=N(lw["flux_up"]), lw_flux_dn=N(lw["flux_dn"]), lw_flux_net=N(lw["flux_net"]),
+                sw_flux_up=N(sw["flux_up"]), sw_flux_dn=N(sw["flux_dn"]), sw_flux_dn_dir=N(sw["flux_dn_dir"]), sw_flux_net=N(sw["flux_net"]),
+                lw_tau=N(lw["tau"]), sw_tau=N(sw["tau"]), ssa=N(sw["ssa"]), g=N(sw["g"]),
+                lay_source=N(lw["lay_src"]), lev_source=N(lw["lev_src"]),
+                lw_gpt_up=N(lw["gpt_flux_up"]), sw_gpt_dn=N(sw["gpt_flux_dn"]))
+
+
+def read_output(d):
+    dims, v = rrxio.read(os.path.join(d, "rte_rrtmgp_output.nc"))
+    return dims, {k: a[0].squeeze(axis=-2) if a[0].ndim >= 3 else a[0] for k, a in v.items()}
+
+
+@pytest.mark.parametrize("clouds", [False, True])
+def test_driver_matches_pipeline_and_oracle(case, clouds, hip_f64, oracle_f64):
+    flags = ["--cloud-optics"] if clouds else []
+    assert run_driver(case["dir"], *flags, "--output-optical") == 0
+    _, out = read_output(case["dir"])
+    hip = reference_fluxes(hip_f64, case, clouds)
+    orc = reference_fluxes(oracle_f64, case, clouds)
+    for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net",
+              "lw_tau", "sw_tau", "ssa", "g", "lay_source", "lev_source"):
+        assert cases.rel_err(out[k], hip[k]) <= 1e-11, f"C++ classes vs launcher pipeline: {k}"
+        assert cases.rel_err(out[k], orc[k]) <= (1e-7 if k.startswith("sw_flux") else 1e-9), f"C++ classes vs CPU oracle: {k}"
+
+
+def test_driver_column_blocks_bands_and_broadband_mode(case, hip_f64):
+    hip = reference_fluxes(hip_f64, case, True)
+    # 45 columns in blocks of 7 (6 full blocks + a residual of 3), with band fluxes
+    assert run_driver(case["dir"], "--cloud-optics", "--output-bnd-fluxes", env={"RRX_COL_BLOCK": "7"}) == 0
+    _, out = read_output(case["dir"])
+    for k in ("lw_flux_up", "lw_flux_dn", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir"):
+        assert cases.rel_err(out[k], hip[k]) <= 1e-11, k
+    lims = case["kl"].band_lims_gpt
+    for ib in range(KW["nbnd"]):
+        want = hip["lw_gpt_up"][lims[ib, 0]-1:lims[ib, 1]].sum(axis=0)
+        assert cases.rel_err(out["lw_bnd_flux_up"][ib], want) <= 1e-12
+        want = hip["sw_gpt_dn"][lims[ib, 0]-1:lims[ib, 1]].sum(axis=0)
+        assert cases.rel_err(out["sw_bnd_flux_dn"][ib], want) <= 1e-12
+    assert cases.rel_err(out["lw_bnd_flux_up"].sum(axis=0), hip["lw_flux_up"]) <= 1e-12
+    # broadband solvers (the CPU path's convention): same fluxes without per-g-point arrays
+    assert run_driver(case["dir"], "--cloud-optics", "--broadband-solvers", "--no-delta-cloud") == 0
+    assert run_driver(case["dir"], "--cloud-optics", "--broadband-solvers") == 0
+    _, out = read_output(case["dir"])
+    for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net"):
+        assert cases.rel_err(out[k], hip[k]) <= 1e-11, k
+
+
+def test_driver_error_behaviour(case):
+    # same contract as the reference's main(): any exception -> message + exit status 1
+    assert run_driver(case["dir"], "--bogus-option") == 1
+    assert run_driver(case["dir"], "--aerosol-optics") == 1
+    assert run_driver(os.path.dirname(case["dir"])) == 1        # no input file there

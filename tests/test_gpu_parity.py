@@ -2,7 +2,7 @@
 
 Tolerances (relative, cases.rel_err): the north star asks for fluxes within 1e-6 relative of the CPU path; the
 kernels are held to much tighter bounds where the arithmetic allows:
-  fp64 kernels vs golden / oracle : 1e-10   (scan re-association and libm differences only)
+  fp64 kernels vs golden / oracle : 1e-10   (scan re-association and libm differences only); SW solver fluxes 1e-7
   fp32 kernels vs fp32 golden     : 2e-4    (fp32 round-off through 30-140 layer recurrences)
   fp64 full solve vs oracle       : 1e-9 on broadband fluxes
 """
@@ -62,7 +62,7 @@ def _solve_both(hip, orc, kind, ncol, nlay, top_at_1, clouds, ngpt=64, nbnd=4, *
 def test_full_solve_matches_oracle(kind, ncol, nlay, top_at_1, clouds, hip_f64, oracle_f64):
     h, o = _solve_both(hip_f64, oracle_f64, kind, ncol, nlay, top_at_1, clouds)
     for k in o:
-        tol = 1e-9
+        tol = 1e-7 if (kind == "sw" and "flux" in k) else 1e-9      # see cases.Checker.sw_tol
         e = cases.rel_err(h[k], o[k])
         assert e <= tol, f"{kind} {k}: {e:.3e}"
 
