@@ -106,7 +106,8 @@ def main():
     solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband)
     gathered = None
     if world > 1 and not args.no_gather:
-        gathered = torch.empty((world,) + tuple(solver.fluxes.shape), dtype=solver.fluxes.dtype, device=device)
+        shp = tuple(solver.fluxes.shape)
+        gathered = torch.empty((world*shp[0],) + shp[1:], dtype=solver.fluxes.dtype, device=device)
 
     def one_step():
         F = solver.step()

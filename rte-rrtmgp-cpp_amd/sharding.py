@@ -1,0 +1,55 @@
+"""Column sharding over the GPUs of one node.
+
+Columns are fully independent through the whole path (g-points only meet in the broadband sum, which stays on the device
+that owns the column), so rank r of N owns one contiguous column range and runs the complete LW+SW solve on it; the only
+communication is ONE all-gather of the packed broadband fluxes per solve (RCCL over xGMI on GPUs: backend "nccl"; gloo
+in the CPU tests). The reference has no multi-device code at all."""
+import torch
+import torch.distributed as dist
+
+
+def column_range(rank, world, ncol_total):
+    """Contiguous, balanced partition: the first (ncol_total % world) ranks get one extra column. Returns [start, stop)."""
+    base, extra = divmod(ncol_total, world)
+    start = rank*base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_atmosphere(atm, rank, world):
+    """Column slice of a host-side synthetic.Atmosphere for this rank (numpy, column index is the LAST array axis)."""
+    import numpy as np
+    from .synthetic import Atmosphere
+    s, e = column_range(rank, world, atm.ncol)
+    out = {}
+    for k, v in atm.__dict__.items():
+        if isinstance(v, np.ndarray):
+            if k in ("emis_sfc", "sfc_alb_dir", "sfc_alb_dif"):      # (ncol, nbnd)
+                out[k] = np.ascontiguousarray(v[s:e])
+            else:
+                out[k] = np.ascontiguousarray(v[..., s:e])
+        elif isinstance(v, dict):
+            out[k] = {n: np.ascontiguousarray(a[..., s:e]) for n, a in v.items()}
+        else:
+            out[k] = v
+    out["ncol"] = e - s
+    return Atmosphere(**out)
+
+
+def gather_fluxes(local, ncol_total, group=None):
+    """All-gather packed fluxes (nflux, nlev, ncol_local) -> (nflux, nlev, ncol_total) on every rank.
+    Uneven shards are padded to the largest one so that a single all_gather_into_tensor suffices."""
+    world = dist.get_world_size(group)
+    nmax = -(-ncol_total // world)
+    nflux, nlev, nloc = local.shape
+    if nloc < nmax:
+        pad = torch.zeros((nflux, nlev, nmax), dtype=local.dtype, device=local.device)
+        pad[..., :nloc] = local
+        local = pad
+    out = torch.empty((world*nflux, nlev, nmax), dtype=local.dtype, device=local.device)   # concatenated along dim 0
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    out = out.view(world, nflux, nlev, nmax)
+    parts = []
+    for r in range(world):
+        s, e = column_range(r, world, ncol_total)
+        parts.append(out[r, :, :, :e - s])
+    return torch.cat(parts, dim=-1)
