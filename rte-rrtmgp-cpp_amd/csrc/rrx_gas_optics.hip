@@ -92,22 +92,26 @@ interpolation_kernel(
 }
 
 
-// Per-workgroup index of the minor contributors overlapping each 16-g-point chunk, built in LDS.
-// Entry layout (ints): lists[r][c] = { count, then per item {imnr, gpt_start, gpt_end, kminor_start-1-gpt_start} }
-// in ascending imnr (deterministic summation order, identical to the reference's sequential loop over imnr).
+// Per-workgroup tables in LDS, built once per workgroup:
+//   gflav[r][ig]           flavor (0-based) of g-point ig in regime r (0 = lower, 1 = upper atmosphere)
+//   lists[r][c] = { count, then per item {imnr, gpt_start, gpt_end, kminor_start-1-gpt_start, flavor} } : the minor
+//   contributors overlapping 16-g-point chunk c, in ascending imnr (deterministic summation order, identical to the
+//   reference's sequential loop over imnr).
+// With these, the g-point loop has no dependent global loads for metadata.
+constexpr int ITEM = 5;
 struct MinorIndex
 {
     const int* base; int stride_c; int stride_r;
     __device__ __forceinline__ int count(int r, int c) const { return base[r*stride_r + c*stride_c]; }
-    __device__ __forceinline__ const int* item(int r, int c, int i) const { return base + r*stride_r + c*stride_c + 1 + 4*i; }
+    __device__ __forceinline__ const int* item(int r, int c, int i) const { return base + r*stride_r + c*stride_c + 1 + ITEM*i; }
 };
 
 __device__ inline MinorIndex build_minor_index(
-        int* lds, const int nchunk, const int nmax,
+        int* lds, const int nchunk, const int nmax, const int* __restrict__ gpoint_flavor,
         const int nminorlower, const int* __restrict__ lim_lower, const int* __restrict__ kst_lower,
         const int nminorupper, const int* __restrict__ lim_upper, const int* __restrict__ kst_upper)
 {
-    MinorIndex mi{lds, 1 + 4*nmax, nchunk*(1 + 4*nmax)};
+    MinorIndex mi{lds, 1 + ITEM*nmax, nchunk*(1 + ITEM*nmax)};
     const int tid = threadIdx.y*blockDim.x + threadIdx.x;
     const int nthr = blockDim.x*blockDim.y;
     for (int w = tid; w < 2*nchunk; w += nthr)
@@ -123,27 +127,33 @@ __device__ inline MinorIndex build_minor_index(
             const int lo = lim[2*i]-1, hi = lim[2*i+1];          // [lo, hi) zero-based
             if (lo < (c+1)*GCH && hi > c*GCH)
             {
-                out[1 + 4*cnt + 0] = i; out[1 + 4*cnt + 1] = lo; out[1 + 4*cnt + 2] = hi;
-                out[1 + 4*cnt + 3] = kst[i]-1 - lo;
+                int* it = out + 1 + ITEM*cnt;
+                it[0] = i; it[1] = lo; it[2] = hi; it[3] = kst[i]-1 - lo; it[4] = gpoint_flavor[2*lo + r] - 1;
                 ++cnt;
             }
         }
         out[0] = cnt;
     }
-    __syncthreads();
     return mi;
 }
 
-constexpr int MAXI = 12;     // minor scalings cached in LDS per (thread, chunk); further ones are recomputed
+constexpr int SL = 6;        // minor contributors of a chunk held in registers; further ones take a slower loop
+struct Slots { int lo[SL], hi[SL], koff[SL], mf[SL]; };
+
+// element at BYTE offset `boff` (32-bit, unsigned) from a wave-uniform base: lets the compiler use the
+// scalar-base + 32-bit-vector-offset form of global_load instead of 64-bit per-lane address arithmetic
+template<typename F>
+__device__ __forceinline__ F ld(const F* __restrict__ base, const unsigned boff)
+{
+    return *reinterpret_cast<const F*>(reinterpret_cast<const char*>(base) + boff);
+}
 
 
 // MODE 0: tau += major + minor            (compute_tau_absorption, reference semantics: caller zeroes tau)
 // MODE 1: tau/ssa/g = fused absorption + Rayleigh + combine   (SW gas optics in one pass)
 // major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
 // minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
-// Assumes, like the reference's data (create_gpoint_flavor, src/Gas_optics_rrtmgp.cpp:331-363), that a minor
-// interval does not straddle bands of different flavor; if it does the flavor of its first g-point is used,
-// exactly as in the reference kernel.
+// A minor interval uses the flavor of its first g-point, exactly as the reference kernel (:533).
 template<typename F, int MODE>
 __global__ void __launch_bounds__(256)
 tau_absorption_kernel(
@@ -163,16 +173,24 @@ tau_absorption_kernel(
         const F* __restrict__ krayl,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
 {
-    extern __shared__ double lds_raw[];
+    extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
-    F* scal = reinterpret_cast<F*>(lds_raw);                                   // [MAXI][256]
-    int* lists = reinterpret_cast<int*>(scal + MAXI*256);
-    const MinorIndex mi = build_minor_index(lists, nchunk, nmax,
+    int* gflav = lds_int;                                   // [2][ngpt]
+    int* gchg = lds_int + 2*ngpt;                           // [ngpt] 1 where the flavor of either regime changes
+    int* lists = lds_int + 3*ngpt;
+    {
+        const int tid = threadIdx.y*blockDim.x + threadIdx.x;
+        for (int w = tid; w < 2*ngpt; w += blockDim.x*blockDim.y)
+            gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
+        for (int w = tid; w < ngpt; w += blockDim.x*blockDim.y)
+            gchg[w] = (w > 0 && (gpoint_flavor[2*w] != gpoint_flavor[2*w-2] || gpoint_flavor[2*w+1] != gpoint_flavor[2*w-1])) ? 1 : 0;
+    }
+    const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gpoint_flavor,
             nminorlower, minor_limits_gpt_lower, kminor_start_lower,
             nminorupper, minor_limits_gpt_upper, kminor_start_upper);
+    __syncthreads();
 
-    const int tid = threadIdx.y*blockDim.x + threadIdx.x;
     const int icol = blockIdx.x*blockDim.x + threadIdx.x;
     const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
@@ -185,6 +203,7 @@ tau_absorption_kernel(
     const int s_eta = ntemp, s_prs = ntemp*neta;
     const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
     const int tn = ntemp*neta;
+    constexpr unsigned SZ = sizeof(F);
 
     const F pl = play[idx], tl = tlay[idx];
     const F cdry0 = col_gas[idx];                         // col_gas(:,:,0) = col_dry
@@ -192,7 +211,6 @@ tau_absorption_kernel(
     F ray_fac = F(0.);
     if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
 
-    const F* kminor = itropo == 0 ? kminor_lower : kminor_upper;
     const Bool* swd = itropo == 0 ? minor_scales_with_density_lower : minor_scales_with_density_upper;
     const Bool* sbc = itropo == 0 ? scale_by_complement_lower : scale_by_complement_upper;
     const int* imn = itropo == 0 ? idx_minor_lower : idx_minor_upper;
@@ -215,11 +233,12 @@ tau_absorption_kernel(
         return scaling;
     };
 
-    // interpolation state of the current flavor
+    // interpolation state of the current flavor; LUT offsets are BYTE offsets within one g-point slab / table row
     int cur_flav = -1;
     F fm0=0, fm1=0, fm2=0, fm3=0, fm4=0, fm5=0, fm6=0, fm7=0, cm0=0, cm1=0, fn0=0, fn1=0, fn2=0, fn3=0;
-    int o00=0, o01=0, o10=0, o11=0;            // kmajor offsets (without g-point) for the two temperatures
-    int m0a=0, m0b=0, m1a=0, m1b=0;            // kminor / krayl offsets
+    unsigned b00=0, b01=0, b10=0, b11=0;       // kmajor: (jt-1 | jt) x (jp-1 | jp), lower eta node
+    unsigned q0a=0, q0b=0, q1a=0, q1b=0;       // kminor / krayl
+    const unsigned beta = unsigned(s_eta)*SZ;
 
     auto load_flavor = [&](const int iflav)
     {
@@ -231,69 +250,152 @@ tau_absorption_kernel(
         const int je0 = jeta[2*cell], je1 = jeta[2*cell+1];
         const F* fn = fminor + 4*cell;
         fn0=fn[0]; fn1=fn[1]; fn2=fn[2]; fn3=fn[3];
-        o00 = (jt-1) + (je0-1)*s_eta + (jp-1)*s_prs;  o01 = o00 + s_prs;
-        o10 =  jt    + (je1-1)*s_eta + (jp-1)*s_prs;  o11 = o10 + s_prs;
-        m0a = (jt-1) + (je0-1)*ntemp; m0b = m0a + ntemp;
-        m1a =  jt    + (je1-1)*ntemp; m1b = m1a + ntemp;
+        b00 = unsigned((jt-1) + (je0-1)*s_eta + (jp-1)*s_prs)*SZ;  b01 = b00 + unsigned(s_prs)*SZ;
+        b10 = unsigned( jt    + (je1-1)*s_eta + (jp-1)*s_prs)*SZ;  b11 = b10 + unsigned(s_prs)*SZ;
+        q0a = unsigned((jt-1) + (je0-1)*ntemp)*SZ; q0b = q0a + unsigned(ntemp)*SZ;
+        q1a = unsigned( jt    + (je1-1)*ntemp)*SZ; q1b = q1a + unsigned(ntemp)*SZ;
+    };
+
+    // minor absorption of a contributor whose flavor is not the band's (does not occur in rrtmgp-data; kept exact)
+    auto minor_other_flavor = [&](const int mflav, const F* km) -> F
+    {
+        const size_t cell = idx + size_t(mflav)*ncl;
+        const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
+        const F* fn = fminor + 4*cell;
+        return fn[0]*km[(jt-1) + (j0-1)*ntemp] + fn[1]*km[(jt-1) + j0*ntemp]
+             + fn[2]*km[ jt    + (j1-1)*ntemp] + fn[3]*km[ jt    + j1*ntemp];
+    };
+
+    // G g-points at a time: all LUT gathers of the group are issued before the first use, so one memory round trip is
+    // paid per group instead of per g-point (a g-point-at-a-time loop is latency-bound: 78 % of wave cycles in s_waitcnt).
+    constexpr int G = 4;
+    auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
+    {
+        int igs[G];
+        #pragma unroll
+        for (int u=0; u<G; ++u) igs[u] = min(ig0 + u, gend-1);
+
+        F kv[G][8];
+        #pragma unroll
+        for (int u=0; u<G; ++u)
+        {
+            const F* k = kmajor + size_t(igs[u])*s_gpt;            // wave-uniform base
+            kv[u][0] = ld(k, b00); kv[u][1] = ld(k, b00 + beta); kv[u][2] = ld(k, b01); kv[u][3] = ld(k, b01 + beta);
+            kv[u][4] = ld(k, b10); kv[u][5] = ld(k, b10 + beta); kv[u][6] = ld(k, b11); kv[u][7] = ld(k, b11 + beta);
+        }
+        F rv[G][4];
+        if constexpr (MODE == 1)
+        {
+            #pragma unroll
+            for (int u=0; u<G; ++u)
+            {
+                const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(igs[u])*tn;
+                rv[u][0] = ld(kr, q0a); rv[u][1] = ld(kr, q0b); rv[u][2] = ld(kr, q1a); rv[u][3] = ld(kr, q1b);
+            }
+        }
+        F told[G];
+        if constexpr (MODE == 0)
+        {
+            #pragma unroll
+            for (int u=0; u<G; ++u) told[u] = tau[idx + size_t(igs[u])*ncl];
+        }
+
+        F t[G];
+        #pragma unroll
+        for (int u=0; u<G; ++u)
+            t[u] = cm0 * (fm0*kv[u][0] + fm1*kv[u][1] + fm2*kv[u][2] + fm3*kv[u][3])
+                 + cm1 * (fm4*kv[u][4] + fm5*kv[u][5] + fm6*kv[u][6] + fm7*kv[u][7]);
+
+        const F* kmin = itropo == 0 ? kminor_lower : kminor_upper;
+        #pragma unroll
+        for (int i=0; i<SL; ++i)
+        {
+            if (i < n && ig0 < sl.hi[i] && ig0 + G > sl.lo[i])      // the contributor overlaps this group
+            {
+                F mv[G][4];
+                #pragma unroll
+                for (int u=0; u<G; ++u)
+                {
+                    const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
+                    const F* km = kmin + size_t(kg + sl.koff[i])*tn;
+                    if (sl.mf[i] == cur_flav) { mv[u][0] = ld(km, q0a); mv[u][1] = ld(km, q0b); mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                    else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
+                }
+                #pragma unroll
+                for (int u=0; u<G; ++u)
+                {
+                    if (igs[u] >= sl.lo[i] && igs[u] < sl.hi[i])
+                    {
+                        const F kk = (sl.mf[i] == cur_flav) ? fn0*mv[u][0] + fn1*mv[u][1] + fn2*mv[u][2] + fn3*mv[u][3] : mv[u][0];
+                        t[u] += kk * sc[i];
+                    }
+                }
+            }
+        }
+        for (int i=SL; i<n; ++i)                          // more than SL contributors in one chunk: rare
+        {
+            const int* it = mi.item(itropo, c, i);
+            #pragma unroll
+            for (int u=0; u<G; ++u)
+                if (igs[u] >= it[1] && igs[u] < it[2])
+                {
+                    const F* km = kmin + size_t(igs[u] + it[3])*tn;
+                    const F kk = (it[4] == cur_flav) ? fn0*ld(km, q0a) + fn1*ld(km, q0b) + fn2*ld(km, q1a) + fn3*ld(km, q1b)
+                                                     : minor_other_flavor(it[4], km);
+                    t[u] += kk * minor_scaling(it[0]);
+                }
+        }
+
+        #pragma unroll
+        for (int u=0; u<G; ++u)
+        {
+            if (ig0 + u < gend)
+            {
+                const size_t o = idx + size_t(ig0 + u)*ncl;
+                if constexpr (MODE == 0)
+                {
+                    tau[o] = told[u] + t[u];
+                }
+                else
+                {
+                    const F ray = ray_fac * (fn0*rv[u][0] + fn1*rv[u][1] + fn2*rv[u][2] + fn3*rv[u][3]);
+                    const F tt = t[u] + ray;
+                    tau[o] = tt;
+                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
+                    g[o] = F(0.);
+                }
+            }
+        }
     };
 
     for (int c=0; c<nchunk; ++c)
     {
         const int c0 = c*GCH;
         const int n = mi.count(itropo, c);
-
-        // per-cell scaling of every minor contributor of this chunk, cached in LDS (dynamic indexing)
-        for (int i=0; i<min(n, MAXI); ++i)
-            scal[i*256 + tid] = minor_scaling(mi.item(itropo, c, i)[0]);
-
         const int gend = min(c0 + GCH, ngpt);
-        #pragma unroll 2
-        for (int ig=c0; ig<gend; ++ig)
+
+        // this chunk's minor contributors: parameters and per-cell scaling in registers
+        Slots sl; F sc[SL];
+        #pragma unroll
+        for (int i=0; i<SL; ++i)
         {
-            const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
+            const int* it = mi.item(itropo, c, min(i, max(n-1, 0)));
+            sl.lo[i] = it[1]; sl.hi[i] = it[2]; sl.koff[i] = it[3]; sl.mf[i] = it[4];
+            sc[i] = F(0.);
+            if (i < n) sc[i] = minor_scaling(it[0]);
+        }
+
+        for (int ig0=c0; ig0<gend; )
+        {
+            // a group never straddles a flavor change (of either regime, so that group bounds stay wave-uniform)
+            const int iflav = gflav[itropo*ngpt + ig0];
             if (iflav != cur_flav) load_flavor(iflav);
-
-            const F* k = kmajor + size_t(ig)*s_gpt;
-            F t = cm0 * (fm0*k[o00] + fm1*k[o00 + s_eta] + fm2*k[o01] + fm3*k[o01 + s_eta])
-                + cm1 * (fm4*k[o10] + fm5*k[o10 + s_eta] + fm6*k[o11] + fm7*k[o11 + s_eta]);
-
-            for (int i=0; i<n; ++i)
-            {
-                const int* it = mi.item(itropo, c, i);
-                if (ig >= it[1] && ig < it[2])
-                {
-                    const F sc = i < MAXI ? scal[i*256 + tid] : minor_scaling(it[0]);
-                    const F* km = kminor + size_t(ig + it[3])*tn;
-                    const int mflav = gpoint_flavor[2*it[1] + itropo] - 1;
-                    F kk;
-                    if (mflav == cur_flav)
-                        kk = fn0*km[m0a] + fn1*km[m0b] + fn2*km[m1a] + fn3*km[m1b];
-                    else
-                    {
-                        const size_t cell = idx + size_t(mflav)*ncl;
-                        const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
-                        const F* fn = fminor + 4*cell;
-                        kk = fn[0]*km[(jt-1) + (j0-1)*ntemp] + fn[1]*km[(jt-1) + j0*ntemp]
-                           + fn[2]*km[ jt    + (j1-1)*ntemp] + fn[3]*km[ jt    + j1*ntemp];
-                    }
-                    t += kk * sc;
-                }
-            }
-
-            const size_t o = idx + size_t(ig)*ncl;
-            if constexpr (MODE == 0)
-            {
-                tau[o] += t;
-            }
-            else
-            {
-                const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(ig)*tn;
-                const F ray = ray_fac * (fn0*kr[m0a] + fn1*kr[m0b] + fn2*kr[m1a] + fn3*kr[m1b]);
-                const F tt = t + ray;
-                tau[o] = tt;
-                ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
-                g[o] = F(0.);
-            }
+            int ge = min(ig0 + G, gend);
+            #pragma unroll
+            for (int u=G-1; u>=1; --u)
+                if (ig0 + u < gend && gchg[ig0 + u]) ge = ig0 + u;
+            gpoint_group(ig0, ge, c, n, sl, sc);
+            ig0 = ge;
         }
     }
 }
@@ -542,7 +644,7 @@ int tau_absorption_impl(
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = std::max(nminorlower, nminorupper);
-    const size_t lds = size_t(MAXI)*256*sizeof(F) + size_t(2)*nchunk*(1 + 4*nmax)*sizeof(int);
+    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax))*sizeof(int);
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));

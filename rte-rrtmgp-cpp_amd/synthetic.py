@@ -17,6 +17,7 @@ Array convention: numpy arrays are C-ordered with REVERSED dimensions, so that t
 column-major, column-fastest layout of the reference: Fortran (ncol,nlay,ngpt)  <->  numpy shape (ngpt,nlay,ncol).
 """
 from dataclasses import dataclass, field
+import os
 import numpy as np
 
 GAS_NAMES = ["h2o", "co2", "o3", "n2o", "ch4", "o2", "n2"]      # 1-based gas indices 1..7 in col_gas
@@ -278,6 +279,8 @@ def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=
 
     dT = rng.uniform(-1.0, 1.0, size=ncol)
     dq = rng.uniform(0.95, 1.05, size=ncol)
+    if os.environ.get("RRX_SYNTH_IDENTICAL_COLUMNS"):        # diagnostic only: the reference's own RCEMIP input
+        dT[:] = 0.0; dq[:] = 1.0
 
     def col2d(prof):
         return np.repeat(prof[:, None], ncol, axis=1)
