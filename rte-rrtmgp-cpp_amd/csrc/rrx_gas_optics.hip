@@ -508,6 +508,10 @@ planck_source_kernel(
 {
     extern __shared__ double lds_raw[];
     F* pf = reinterpret_cast<F*>(lds_raw);            // [GCH][PL+1][64]; slot 0 = layer below the workgroup
+    int* gflav = reinterpret_cast<int*>(pf + GCH*(PL+1)*64);   // [2][ngpt] flavor (0-based) per regime and g-point
+    for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*PL)
+        gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
+    __syncthreads();
 
     const int tx = threadIdx.x, ly = threadIdx.y;
     const int icol_raw = blockIdx.x*64 + tx;
@@ -542,23 +546,43 @@ planck_source_kernel(
     int cur_flav = -1, cur_flav_m1 = -1, cur_bnd = -1;
     F b_lay = 0, b_lev = 0, b_levp = 0, b_sfc = 0, b_sfc2 = 0;
 
+    // Planck fractions of up to PG g-points of one cell: all 8*PG gathers are issued before the first use
+    constexpr int PG = 4;
+    auto fractions = [&](CellInterp<F>& ci, int& cur, const size_t cell_idx, const int itr, const int ig0, const int gend, const int slot)
+    {
+        for (int ig=ig0; ig<gend; )
+        {
+            const int fl = gflav[itr*ngpt + ig];
+            if (fl != cur) { cur = fl; ci.load(cell_idx + size_t(fl)*ncl, fmajor, jeta); }
+            int ge = min(ig + PG, gend);
+            #pragma unroll
+            for (int u=PG-1; u>=1; --u)
+                if (ig + u < gend && gflav[itr*ngpt + ig + u] != fl) ge = ig + u;
+            F v[PG][8];
+            #pragma unroll
+            for (int u=0; u<PG; ++u)
+            {
+                const F* p = pfracin + size_t(min(ig + u, ge-1))*s_gpt;
+                v[u][0] = p[(ci.jt-1) + (ci.je[0]-1)*s_eta + (ci.jp-1)*s_prs]; v[u][1] = p[(ci.jt-1) + ci.je[0]*s_eta + (ci.jp-1)*s_prs];
+                v[u][2] = p[(ci.jt-1) + (ci.je[0]-1)*s_eta +  ci.jp   *s_prs]; v[u][3] = p[(ci.jt-1) + ci.je[0]*s_eta +  ci.jp   *s_prs];
+                v[u][4] = p[ ci.jt    + (ci.je[1]-1)*s_eta + (ci.jp-1)*s_prs]; v[u][5] = p[ ci.jt    + ci.je[1]*s_eta + (ci.jp-1)*s_prs];
+                v[u][6] = p[ ci.jt    + (ci.je[1]-1)*s_eta +  ci.jp   *s_prs]; v[u][7] = p[ ci.jt    + ci.je[1]*s_eta +  ci.jp   *s_prs];
+            }
+            #pragma unroll
+            for (int u=0; u<PG; ++u)
+                if (ig + u < ge)
+                    pf[((ig + u - ig0)*(PL+1) + slot)*64 + tx] =
+                        (ci.fm[0]*v[u][0] + ci.fm[1]*v[u][1] + ci.fm[2]*v[u][2] + ci.fm[3]*v[u][3])
+                      + (ci.fm[4]*v[u][4] + ci.fm[5]*v[u][5] + ci.fm[6]*v[u][6] + ci.fm[7]*v[u][7]);
+            ig = ge;
+        }
+    };
+
     for (int c0=0; c0<ngpt; c0+=GCH)
     {
         const int gend = min(c0 + GCH, ngpt);
-        for (int ig=c0; ig<gend; ++ig)
-        {
-            const int u = ig - c0;
-            const F* p = pfracin + size_t(ig)*s_gpt;
-            const int iflav = gpoint_flavor[itropo + 2*ig] - 1;
-            if (iflav != cur_flav) { cur_flav = iflav; own.load(idx + iflav*ncl, fmajor, jeta); }
-            pf[(u*(PL+1) + ly+1)*64 + tx] = own.pfrac(p, s_eta, s_prs);
-            if (halo)
-            {
-                const int iflav_m1 = gpoint_flavor[itropo_m1 + 2*ig] - 1;
-                if (iflav_m1 != cur_flav_m1) { cur_flav_m1 = iflav_m1; prev.load(idx - ncol + iflav_m1*ncl, fmajor, jeta); }
-                pf[(u*(PL+1))*64 + tx] = prev.pfrac(p, s_eta, s_prs);
-            }
-        }
+        fractions(own, cur_flav, idx, itropo, c0, gend, ly+1);
+        if (halo) fractions(prev, cur_flav_m1, idx - ncol, itropo_m1, c0, gend, 0);
         __syncthreads();
 
         for (int ig=c0; ig<gend; ++ig)
@@ -758,7 +782,7 @@ int rrx_compute_planck_source##SFX( \
     RRX_TRY \
     (void)nbnd; (void)nflav; (void)band_lims_gpt; \
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
-    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F), static_cast<hipStream_t>(stream)>>>( \
+    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F) + size_t(2)*ngpt*sizeof(int), static_cast<hipStream_t>(stream)>>>( \
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
             gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac); \
     RRX_CATCH("rrx_compute_planck_source") \
