@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--sw-variant", type=int, default=0)
     ap.add_argument("--cpu-cols", type=int, default=1200, help="columns of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
     args = ap.parse_args()
 
     import torch
@@ -103,7 +104,7 @@ def main():
     # rank r owns global columns [r*ncol, (r+1)*ncol): different seed offset per rank, same generator
     atm0 = synthetic.make_atmosphere(args.ncol, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234 + rank)
     atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
-    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband)
+    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap)
     gathered = None
     if world > 1 and not args.no_gather:
         shp = tuple(solver.fluxes.shape)

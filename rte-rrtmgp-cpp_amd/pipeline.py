@@ -138,9 +138,13 @@ class ResidentSolver:
 
     STAGES = ("lw_gas_optics", "lw_planck", "lw_solver", "lw_reduce", "sw_gas_optics", "sw_solver", "sw_reduce")
 
-    def __init__(self, be, kd_lw, kd_sw, atm, do_broadband=False):
+    def __init__(self, be, kd_lw, kd_sw, atm, do_broadband=False, overlap=False):
         import torch
         self.torch = torch
+        # overlap: LW and SW chains are independent, so they can run on two HIP streams and share the chip (the gather-
+        # bound gas-optics kernels of one chain fill in next to the HBM-bound solver of the other)
+        self.overlap = overlap
+        self.streams = [torch.cuda.Stream(device=be.device), torch.cuda.Stream(device=be.device)] if overlap else None
         self.be, self.kd_lw, self.kd_sw, self.atm = be, kd_lw, kd_sw, atm
         self.do_broadband = do_broadband
         ncol, nlay = atm.ncol, atm.nlay
@@ -162,6 +166,7 @@ class ResidentSolver:
         self.alb_dir = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dir, ng_s)
         self.alb_dif = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dif, ng_s)
         self.events = None
+        self.col_dry2 = None
 
     def enable_stage_events(self, nsteps):
         ev = self.torch.cuda.Event
@@ -177,6 +182,8 @@ class ResidentSolver:
 
     def step(self):
         be, atm = self.be, self.atm
+        if self.overlap and self.col_dry2 is None:
+            self.col_dry2 = be.empty(tuple(self.col_dry.shape))
         rec = None
         if self.events is not None and self._istep < len(self.events):
             rec = self.events[self._istep]
@@ -184,14 +191,20 @@ class ResidentSolver:
 
         def mark(stage, end=False):
             if rec is not None:
-                rec[stage][1 if end else 0].record(self.torch.cuda.current_stream(be.device))
+                rec[stage][1 if end else 0].record(self.torch.cuda.current_stream(be.device))   # the chain's stream when overlapping
 
         ncol, nlay = atm.ncol, atm.nlay
         F = self.fluxes
-        for kind, kd, buf in (("lw", self.kd_lw, self.lw), ("sw", self.kd_sw, self.sw)):
+        main = self.torch.cuda.current_stream(be.device)
+        for ichain, (kind, kd, buf) in enumerate((("lw", self.kd_lw, self.lw), ("sw", self.kd_sw, self.sw))):
+            if self.overlap:
+                self.streams[ichain].wait_stream(main)
+                ctx = self.torch.cuda.stream(self.streams[ichain])
+                ctx.__enter__()
             mark(kind + "_gas_optics")
-            be._c("get_col_dry", ncol, nlay, atm.vmr["h2o"], atm.p_lev, self.col_dry)
-            col_gas = be.fill_gases(kd, atm.vmr, self.col_dry)
+            col_dry = self.col_dry2 if (self.overlap and ichain == 1) else self.col_dry
+            be._c("get_col_dry", ncol, nlay, atm.vmr["h2o"], atm.p_lev, col_dry)
+            col_gas = be.fill_gases(kd, atm.vmr, col_dry)
             it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
             if kind == "lw":
                 buf["tau"].zero_()
@@ -217,7 +230,7 @@ class ResidentSolver:
                 be.net_broadband_precalc(F[1], F[0], out=F[2])
                 mark("lw_reduce", True)
             else:
-                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, self.col_dry, buf["tau"], buf["ssa"], buf["g"])
+                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], buf["g"])
                 toa = be.spread_col(ncol, kd.solar_source)
                 be.scaling_to_subset(toa, atm.tsi_scaling)
                 mark("sw_gas_optics", True)
@@ -235,4 +248,8 @@ class ResidentSolver:
                     be.sum_broadband(buf["gpt_up"], out=F[3]); be.sum_broadband(buf["gpt_dn"], out=F[4]); be.sum_broadband(buf["gpt_dir"], out=F[5])
                 be.net_broadband_precalc(F[4], F[3], out=F[6])
                 mark("sw_reduce", True)
+            if self.overlap:
+                ctx.__exit__(None, None, None)
+        if self.overlap:
+            main.wait_stream(self.streams[0]); main.wait_stream(self.streams[1])
         return F
