@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--broadband", action="store_true", help="fuse the g-point sum into the solvers (CPU-path semantics)")
     ap.add_argument("--lw-variant", type=int, default=0)
     ap.add_argument("--sw-variant", type=int, default=0)
-    ap.add_argument("--cpu-cols", type=int, default=1200, help="columns of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cols", type=int, default=6000, help="columns of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
     args = ap.parse_args()

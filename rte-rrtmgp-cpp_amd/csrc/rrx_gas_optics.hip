@@ -149,6 +149,21 @@ __device__ __forceinline__ F ld(const F* __restrict__ base, const unsigned boff)
 }
 
 
+// The k tables have temperature as their fastest dimension, so the two temperature nodes of one (eta, pressure) corner
+// are adjacent words: ld2 fetches both with one 2-word load (element-aligned only). The L1 serves a wave's gather at
+// 4 lanes per clock whatever the width per lane (PMC: ~16 cache accesses per 64-lane load), so this halves the cost of
+// every gather whose two temperature nodes share the eta index (je0 == je1; the other lanes issue the second node's
+// loads under their own exec mask).
+template<typename F> struct Pair { F x, y; };
+template<typename F>
+__device__ __forceinline__ Pair<F> ld2(const F* __restrict__ base, const unsigned boff)
+{
+    typedef F Vec2 __attribute__((ext_vector_type(2), aligned(sizeof(F))));
+    const Vec2 v = *reinterpret_cast<const Vec2*>(reinterpret_cast<const char*>(base) + boff);
+    return Pair<F>{v.x, v.y};
+}
+
+
 // MODE 0: tau += major + minor            (compute_tau_absorption, reference semantics: caller zeroes tau)
 // MODE 1: tau/ssa/g = fused absorption + Rayleigh + combine   (SW gas optics in one pass)
 // major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
@@ -235,6 +250,7 @@ tau_absorption_kernel(
 
     // interpolation state of the current flavor; LUT offsets are BYTE offsets within one g-point slab / table row
     int cur_flav = -1;
+    bool same_eta = false;                       // je0 == je1: the jt node sits one word after the jt-1 node
     F fm0=0, fm1=0, fm2=0, fm3=0, fm4=0, fm5=0, fm6=0, fm7=0, cm0=0, cm1=0, fn0=0, fn1=0, fn2=0, fn3=0;
     unsigned b00=0, b01=0, b10=0, b11=0;       // kmajor: (jt-1 | jt) x (jp-1 | jp), lower eta node
     unsigned q0a=0, q0b=0, q1a=0, q1b=0;       // kminor / krayl
@@ -250,6 +266,7 @@ tau_absorption_kernel(
         const int je0 = jeta[2*cell], je1 = jeta[2*cell+1];
         const F* fn = fminor + 4*cell;
         fn0=fn[0]; fn1=fn[1]; fn2=fn[2]; fn3=fn[3];
+        same_eta = (je0 == je1);
         b00 = unsigned((jt-1) + (je0-1)*s_eta + (jp-1)*s_prs)*SZ;  b01 = b00 + unsigned(s_prs)*SZ;
         b10 = unsigned( jt    + (je1-1)*s_eta + (jp-1)*s_prs)*SZ;  b11 = b10 + unsigned(s_prs)*SZ;
         q0a = unsigned((jt-1) + (je0-1)*ntemp)*SZ; q0b = q0a + unsigned(ntemp)*SZ;
@@ -280,8 +297,18 @@ tau_absorption_kernel(
         for (int u=0; u<G; ++u)
         {
             const F* k = kmajor + size_t(igs[u])*s_gpt;            // wave-uniform base
-            kv[u][0] = ld(k, b00); kv[u][1] = ld(k, b00 + beta); kv[u][2] = ld(k, b01); kv[u][3] = ld(k, b01 + beta);
-            kv[u][4] = ld(k, b10); kv[u][5] = ld(k, b10 + beta); kv[u][6] = ld(k, b11); kv[u][7] = ld(k, b11 + beta);
+            const Pair<F> p0 = ld2(k, b00), p1 = ld2(k, b00 + beta), p2 = ld2(k, b01), p3 = ld2(k, b01 + beta);
+            kv[u][0] = p0.x; kv[u][1] = p1.x; kv[u][2] = p2.x; kv[u][3] = p3.x;
+            kv[u][4] = p0.y; kv[u][5] = p1.y; kv[u][6] = p2.y; kv[u][7] = p3.y;
+        }
+        if (!same_eta)
+        {
+            #pragma unroll
+            for (int u=0; u<G; ++u)
+            {
+                const F* k = kmajor + size_t(igs[u])*s_gpt;
+                kv[u][4] = ld(k, b10); kv[u][5] = ld(k, b10 + beta); kv[u][6] = ld(k, b11); kv[u][7] = ld(k, b11 + beta);
+            }
         }
         F rv[G][4];
         if constexpr (MODE == 1)
@@ -290,7 +317,17 @@ tau_absorption_kernel(
             for (int u=0; u<G; ++u)
             {
                 const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(igs[u])*tn;
-                rv[u][0] = ld(kr, q0a); rv[u][1] = ld(kr, q0b); rv[u][2] = ld(kr, q1a); rv[u][3] = ld(kr, q1b);
+                const Pair<F> r0 = ld2(kr, q0a), r1 = ld2(kr, q0b);
+                rv[u][0] = r0.x; rv[u][1] = r1.x; rv[u][2] = r0.y; rv[u][3] = r1.y;
+            }
+            if (!same_eta)
+            {
+                #pragma unroll
+                for (int u=0; u<G; ++u)
+                {
+                    const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(igs[u])*tn;
+                    rv[u][2] = ld(kr, q1a); rv[u][3] = ld(kr, q1b);
+                }
             }
         }
         F told[G];
@@ -318,7 +355,12 @@ tau_absorption_kernel(
                 {
                     const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
                     const F* km = kmin + size_t(kg + sl.koff[i])*tn;
-                    if (sl.mf[i] == cur_flav) { mv[u][0] = ld(km, q0a); mv[u][1] = ld(km, q0b); mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                    if (sl.mf[i] == cur_flav)
+                    {
+                        const Pair<F> m0 = ld2(km, q0a), m1 = ld2(km, q0b);
+                        mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
+                        if (!same_eta) { mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                    }
                     else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
                 }
                 #pragma unroll
@@ -563,10 +605,22 @@ planck_source_kernel(
             for (int u=0; u<PG; ++u)
             {
                 const F* p = pfracin + size_t(min(ig + u, ge-1))*s_gpt;
-                v[u][0] = p[(ci.jt-1) + (ci.je[0]-1)*s_eta + (ci.jp-1)*s_prs]; v[u][1] = p[(ci.jt-1) + ci.je[0]*s_eta + (ci.jp-1)*s_prs];
-                v[u][2] = p[(ci.jt-1) + (ci.je[0]-1)*s_eta +  ci.jp   *s_prs]; v[u][3] = p[(ci.jt-1) + ci.je[0]*s_eta +  ci.jp   *s_prs];
-                v[u][4] = p[ ci.jt    + (ci.je[1]-1)*s_eta + (ci.jp-1)*s_prs]; v[u][5] = p[ ci.jt    + ci.je[1]*s_eta + (ci.jp-1)*s_prs];
-                v[u][6] = p[ ci.jt    + (ci.je[1]-1)*s_eta +  ci.jp   *s_prs]; v[u][7] = p[ ci.jt    + ci.je[1]*s_eta +  ci.jp   *s_prs];
+                // both temperature nodes of a corner with one 2-word load (see ld2); node jt separately where je differs
+                const size_t o00 = (ci.jt-1) + (ci.je[0]-1)*s_eta + (ci.jp-1)*s_prs;
+                const Pair<F> p0 = ld2(p + o00, 0u), p1 = ld2(p + o00 + s_eta, 0u);
+                const Pair<F> p2 = ld2(p + o00 + s_prs, 0u), p3 = ld2(p + o00 + s_prs + s_eta, 0u);
+                v[u][0] = p0.x; v[u][1] = p1.x; v[u][2] = p2.x; v[u][3] = p3.x;
+                v[u][4] = p0.y; v[u][5] = p1.y; v[u][6] = p2.y; v[u][7] = p3.y;
+            }
+            if (ci.je[0] != ci.je[1])
+            {
+                #pragma unroll
+                for (int u=0; u<PG; ++u)
+                {
+                    const F* p = pfracin + size_t(min(ig + u, ge-1))*s_gpt;
+                    v[u][4] = p[ ci.jt    + (ci.je[1]-1)*s_eta + (ci.jp-1)*s_prs]; v[u][5] = p[ ci.jt    + ci.je[1]*s_eta + (ci.jp-1)*s_prs];
+                    v[u][6] = p[ ci.jt    + (ci.je[1]-1)*s_eta +  ci.jp   *s_prs]; v[u][7] = p[ ci.jt    + ci.je[1]*s_eta +  ci.jp   *s_prs];
+                }
             }
             #pragma unroll
             for (int u=0; u<PG; ++u)

@@ -21,12 +21,18 @@ namespace
 {
 using namespace rrx;
 
+#ifndef RRX_LW_DEFAULT_VARIANT
+#define RRX_LW_DEFAULT_VARIANT 5
+#endif
 int g_lw_sync = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
 constexpr int CL = 8;    // column lanes
 constexpr int LL = 8;    // level lanes
 
-template<typename F, int V, int K, bool JAC, bool ACC>
-__global__ void __launch_bounds__(256)
+// W = waves per column group: 1 = the whole column in one wavefront (8 level-lanes x K layers); 2 = the levels of the
+// same 8*V columns spread over 16 level-lanes in two adjacent wavefronts (half the per-lane state, twice the resident
+// waves); the two vertical scans then exchange each wave's total through LDS, one block barrier per scan.
+template<typename F, int V, int K, int W, bool JAC, bool ACC>
+__global__ void __launch_bounds__(256, (W == 2) ? 2 : 1)
 lw_noscat_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
         const F* __restrict__ secants, const F* __restrict__ weights,
@@ -40,16 +46,18 @@ lw_noscat_scan_kernel(
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
     const int igpt = blockIdx.y;
-    const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    const int h = (W == 2) ? (wave & 1) : 0;         // which half of the column this wave holds (0 = TOA side)
+    const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
+    __shared__ F xch[(W == 2) ? 4*V : 1][4][CL];     // wave totals of the two scans
     // The two waves that share each 128-B line (8 columns x 8 B = 64 B per wave when V = 1) must issue their load
     // bursts together, or the second half of every line is fetched from HBM again once L2 has turned over
     // (measured: +26 % FETCH_SIZE without the barrier). No thread leaves before the barrier.
     if (sync_waves) __syncthreads();
-    if (wave_col0 >= ncol) return;                    // wave-uniform
+    if constexpr (W == 1) { if (wave_col0 >= ncol) return; }   // wave-uniform; W == 2 keeps every wave for the barriers
 
     int icol = wave_col0 + cl*V;
     const bool active = icol < ncol;                  // all V columns exist (ncol % V == 0) or none
-    if (!active) icol = wave_col0;                    // harmless duplicate loads, no stores
+    if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;    // harmless duplicate loads, no stores
 
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
@@ -64,7 +72,7 @@ lw_noscat_scan_kernel(
     const Vec<F,V> D = load_cols<F,V>(secants + sfc_idx + size_t(imu)*ncl*ngpt);
     const F w = weights[imu];
 
-    const int t0 = ll*K;
+    const int t0 = (h*LL + ll)*K;
 
     F tr[K][V], sdn[K][V], sup[K][V];
     Vec<F,V> lv[K];
@@ -76,6 +84,20 @@ lw_noscat_scan_kernel(
         const int t = min(t0 + j, nlay);
         const int ml = top_at_1 ? t : nlay - t;
         lv[j] = load_cols<F,V>(lev_source + lev_base + size_t(ml)*ncl);
+    }
+
+    // level below the lane's last layer: first level of the next level-lane; across the wave seam (W == 2) it is loaded
+    Vec<F,V> lv_next;
+    #pragma unroll
+    for (int v=0; v<V; ++v) lv_next.v[v] = shfl(lv[0].v[v], lane + CL);
+    if constexpr (W == 2)
+    {
+        if (ll == LL-1)
+        {
+            const int t = min(t0 + K, nlay);
+            const int ml = top_at_1 ? t : nlay - t;
+            lv_next = load_cols<F,V>(lev_source + lev_base + size_t(ml)*ncl);
+        }
     }
 
     F A[V], Bdn[V], Bup[V];
@@ -98,7 +120,7 @@ lw_noscat_scan_kernel(
             // level source below this layer: next register, or the first level of the next level-lane
             F lev_below;
             if (j < K-1) lev_below = lv[j+1].v[v];
-            else         lev_below = shfl(lv[0].v[v], lane + CL);
+            else         lev_below = lv_next.v[v];
             const F lev_above = lv[j].v[v];
 
             const F tau_loc = tv.v[v] * D.v[v];
@@ -141,11 +163,22 @@ lw_noscat_scan_kernel(
             const F b2 = shfl(b, lane - d*CL);
             if (ll >= d) { b = a*b2 + b; a = a*a2; }
         }
+        F xa = F(1.), xb = F(0.);                               // composite of the levels above this wave's
+        F fa = shfl(a, (LL-1)*CL + cl), fb = shfl(b, (LL-1)*CL + cl);   // composite of the whole column
+        if constexpr (W == 2)
+        {
+            if (ll == LL-1) { xch[4*v+0][wave][cl] = a; xch[4*v+1][wave][cl] = b; }
+            __syncthreads();
+            const F oa = xch[4*v+0][wave^1][cl], ob = xch[4*v+1][wave^1][cl];
+            if (h == 1) { xa = oa; xb = ob; b = a*xb + b; a = a*xa; }
+            fb = (h == 0) ? oa*fb + ob : fa*ob + fb;
+            fa = fa*oa;
+        }
         F ae = shfl(a, lane - CL), be = shfl(b, lane - CL);     // exclusive
-        if (ll == 0) { ae = F(1.); be = F(0.); }
+        if (ll == 0) { ae = xa; be = xb; }
         const F dn_top = (inc_flux != nullptr) ? inc.v[v] / pi : F(0.);
         dn_in[v] = ae*dn_top + be;
-        const F dn_sfc = shfl(a*dn_top + b, (LL-1)*CL + cl);
+        const F dn_sfc = fa*dn_top + fb;
 
         // ---- surface
         const F up_sfc = dn_sfc * (F(1.) - emis.v[v]) + emis.v[v] * ssrc.v[v];
@@ -159,14 +192,21 @@ lw_noscat_scan_kernel(
             const F b2 = shfl(b, lane + d*CL);
             if (ll + d < LL) { b = a*b2 + b; a = a*a2; }
         }
+        xa = F(1.); xb = F(0.);                                 // composite of the levels below this wave's
+        if constexpr (W == 2)
+        {
+            if (ll == 0) { xch[4*v+2][wave][cl] = a; xch[4*v+3][wave][cl] = b; }
+            __syncthreads();
+            if (h == 0) { xa = xch[4*v+2][wave^1][cl]; xb = xch[4*v+3][wave^1][cl]; b = a*xb + b; a = a*xa; }
+        }
         ae = shfl(a, lane + CL); be = shfl(b, lane + CL);
-        if (ll == LL-1) { ae = F(1.); be = F(0.); }
+        if (ll == LL-1) { ae = xa; be = xb; }
         up_in[v] = ae*up_sfc + be;
         if constexpr (JAC) jac_in[v] = ae * emis.v[v] * sjac.v[v];
     }
 
     // ---- replay this lane's K layers and store its K levels (each value is stored as soon as it exists: no staging)
-    if (!active) return;
+    if (!active || wave_col0 >= ncol) return;
     const F scale = pi * w;
 
     auto put = [&](F* __restrict__ arr, const int j, Vec<F,V> val)
@@ -322,7 +362,7 @@ __global__ void sum_gpt_kernel(const size_t ncl_lev, const int ngpt, const F* __
 }
 
 
-template<typename F, int V, int K>
+template<typename F, int V, int K, int W>
 void launch_scan_k(
         hipStream_t st, const dim3 grid, const bool jac, const bool acc,
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
@@ -335,17 +375,17 @@ void launch_scan_k(
 #define RRX_LW_KARGS RRX_LW_ARGS, g_lw_sync
     if (jac)
     {
-        if (acc) lw_noscat_scan_kernel<F,V,K,true,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
-        else     lw_noscat_scan_kernel<F,V,K,true,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        if (acc) lw_noscat_scan_kernel<F,V,K,W,true,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        else     lw_noscat_scan_kernel<F,V,K,W,true,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
     }
     else
     {
-        if (acc) lw_noscat_scan_kernel<F,V,K,false,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
-        else     lw_noscat_scan_kernel<F,V,K,false,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        if (acc) lw_noscat_scan_kernel<F,V,K,W,false,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
+        else     lw_noscat_scan_kernel<F,V,K,W,false,false><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
     }
 }
 
-template<typename F, int V>
+template<typename F, int V, int W>
 bool launch_scan(
         hipStream_t st, const bool jac, const bool acc,
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
@@ -353,15 +393,18 @@ bool launch_scan(
         const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn,
         const F* sfc_src_jac, F* flux_up_jac)
 {
-    const dim3 grid(ceil_div(ncol, 4*CL*V), ngpt);
-    const int need = ceil_div(nlay+1, LL);
-#define RRX_LW_K(KK) if (need <= KK) { launch_scan_k<F,V,KK>(st, grid, jac, acc, RRX_LW_ARGS); return true; }
-    RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) RRX_LW_K(24) RRX_LW_K(33)
+    const dim3 grid(ceil_div(ncol, (4/W)*CL*V), ngpt);
+    const int need = ceil_div(nlay+1, LL*W);
+#define RRX_LW_K(KK) if (need <= KK) { launch_scan_k<F,V,KK,W>(st, grid, jac, acc, RRX_LW_ARGS); return true; }
+    if constexpr (W == 1) { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) RRX_LW_K(24) RRX_LW_K(33) }
+    else                  { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) RRX_LW_K(17) }
 #undef RRX_LW_K
     return false;
 }
 
-int g_lw_variant = 0;   // 0 = auto (scan), 1 = force serial, 2 = scan with V=1, 3 = scan with 128-B segments
+// 0 = default, 1 = serial fallback, 2 = one wave/V=1, 3 = one wave/wide rows, 4 = two waves/64-B rows,
+// 5 = two waves/128-B rows, 6 = one wave/64-B rows
+int g_lw_variant = 0;
 
 #define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac
@@ -395,8 +438,9 @@ int lw_solver_noscat_impl(
         up = ws; dn = ws + nlevcol*ngpt;
     }
 
-    // columns per lane: VDEF*8 lanes*sizeof(F) = 64-B row segments and <= 176 VGPRs (2 waves/SIMD); the wide form
-    // (128-B segments, 1 wave/SIMD) measured the same or slower and is kept as variant 3 for A/B runs.
+    // columns per lane: VDEF*8 lanes*sizeof(F) = 64-B row segments, VMAX = 128-B segments. Measured at C4 (tools/
+    // bench_solvers.py): two waves per column group with 128-B rows (2 waves/SIMD) is the fastest form in both
+    // precisions (fp64 5.4 ms vs 6.0 ms for one wave/64-B rows; fp32 2.4 vs 2.9 ms); the others stay for A/B runs.
     constexpr int VDEF = (sizeof(F) == 8) ? 1 : 2;
     constexpr int VMAX = 2*VDEF;
     for (int imu=0; imu<nmus; ++imu)
@@ -405,12 +449,13 @@ int lw_solver_noscat_impl(
         bool done = false;
         if (g_lw_variant != 1)
         {
-            if (g_lw_variant == 3 && ncol % VMAX == 0)
-                done = launch_scan<F,VMAX>(st, jac, acc, RRX_LW_ARGS_CALL);
-            else if (g_lw_variant != 2 && ncol % VDEF == 0)
-                done = launch_scan<F,VDEF>(st, jac, acc, RRX_LW_ARGS_CALL);
-            else
-                done = launch_scan<F,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+            const int var = (g_lw_variant == 0) ? RRX_LW_DEFAULT_VARIANT : g_lw_variant;
+            if (var == 3 && ncol % VMAX == 0)      done = launch_scan<F,VMAX,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (var == 6 && ncol % VDEF == 0) done = launch_scan<F,VDEF,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (var == 2)                     done = launch_scan<F,1,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (var != 4 && ncol % VMAX == 0) done = launch_scan<F,VMAX,2>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (ncol % VDEF == 0)             done = launch_scan<F,VDEF,2>(st, jac, acc, RRX_LW_ARGS_CALL);
+            if (!done)                             done = launch_scan<F,1,2>(st, jac, acc, RRX_LW_ARGS_CALL);
         }
         if (!done)
         {

@@ -23,9 +23,12 @@ using namespace rrx;
 
 constexpr int CL = 8;
 constexpr int LL = 8;
-constexpr int LOADG = 6;   // layers per load group
+constexpr int LOADG = 6;   // layers per load group   // layers per load group
 #ifndef RRX_SW_MINWAVES
 #define RRX_SW_MINWAVES 1
+#endif
+#ifndef RRX_SW_MINWAVES2
+#define RRX_SW_MINWAVES2 2
 #endif
 
 template<typename F>
@@ -82,8 +85,11 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 }
 
 
-template<typename F, int V, int K>
-__global__ void __launch_bounds__(256, RRX_SW_MINWAVES)
+// W = waves per column group: W = 1 keeps the whole column in one wavefront (8 level-lanes); W = 2 spreads the levels of
+// 8*V columns over 16 level-lanes in two adjacent wavefronts (half the per-lane state, so more resident waves per
+// SIMD); the four vertical scans then exchange each wave's total through LDS with one block barrier per scan.
+template<typename F, int V, int K, int W>
+__global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
@@ -95,6 +101,7 @@ sw_2stream_scan_kernel(
     // two of the six per-layer arrays live here so that the kernel fits 2 waves per SIMD)
     __shared__ F lds_alb[K*V][256];
     __shared__ F lds_dir[K*V][256];
+    __shared__ F xch[(W == 2) ? 8*V : 1][4][CL];    // wave totals of the scans (one slot per scan component)
 
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -102,21 +109,23 @@ sw_2stream_scan_kernel(
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
     const int igpt = blockIdx.y;
-    const int wave_col0 = (blockIdx.x*4 + wave) * (CL*V);
+    const int h = (W == 2) ? (wave & 1) : 0;          // which half of the column this wave holds (0 = TOA side)
+    const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
     // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip)
     if (sync_waves) __syncthreads();
-    if (wave_col0 >= ncol) return;
+    if constexpr (W == 1) { if (wave_col0 >= ncol) return; }
 
+    // W == 2: every wave stays alive until the last barrier; lanes without a column compute on a clamped one
     int icol = wave_col0 + cl*V;
     const bool active = icol < ncol;
-    if (!active) icol = wave_col0;
+    if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;
 
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
     const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
     const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
     const size_t sfc_idx = size_t(igpt)*ncl + icol;
-    const int t0 = ll*K;
+    const int t0 = (h*LL + ll)*K;
 
     const Vec<F,V> mu = load_cols<F,V>(mu0 + icol);
     F mu_inv[V];
@@ -129,11 +138,8 @@ sw_2stream_scan_kernel(
     F sb[K][V];      // source_up        -> beta -> src at level t0+j
     F qb[K][V];      // source_dn        -> q = source_dn*denom -> b
 
-    F Tloc[V];
-    #pragma unroll
-    for (int v=0; v<V; ++v) Tloc[v] = F(1.);
-
-    // ---- (a) two-stream coefficients, (b) direct beam relative to the lane's incoming beam
+    // ---- (a) two-stream coefficients: every layer independent of the others (the direct-beam chain comes afterwards, so
+    //      that the compiler need not keep r_dir, t_dir, t_noscat of all K layers alive next to the result arrays)
     #pragma unroll
     for (int j=0; j<K; ++j)
     {
@@ -150,13 +156,31 @@ sw_2stream_scan_kernel(
         for (int v=0; v<V; ++v)
         {
             const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
-            lds_dir[j*V+v][tid] = Tloc[v];
             rp[j][v] = valid ? ts.r_dif : F(0.);
             al[j][v] = valid ? ts.t_dif : F(1.);
-            sb[j][v] = valid ? ts.r_dir * Tloc[v] : F(0.);
-            qb[j][v] = valid ? ts.t_dir * Tloc[v] : F(0.);
-            Tloc[v] *= valid ? ts.t_noscat : F(1.);
+            sb[j][v] = valid ? ts.r_dir : F(0.);
+            qb[j][v] = valid ? ts.t_dir : F(0.);
+            lds_dir[j*V+v][tid] = valid ? ts.t_noscat : F(1.);
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- (b) direct beam relative to the lane's incoming beam: prefix products of t_noscat, kept in LDS
+    F Tloc[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        F T = F(1.);
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            const F tn = lds_dir[j*V+v][tid];
+            lds_dir[j*V+v][tid] = T;
+            sb[j][v] *= T;
+            qb[j][v] *= T;
+            T *= tn;
+        }
+        Tloc[v] = T;
     }
 
     const Vec<F,V> inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx);
@@ -180,9 +204,18 @@ sw_2stream_scan_kernel(
         }
         F pe = shfl(pr, lane - CL);
         if (ll == 0) pe = F(1.);
+        F ptot = shfl(pr, (LL-1)*CL + cl);
+        if constexpr (W == 2)
+        {
+            if (ll == LL-1) xch[8*v+0][wave][cl] = pr;
+            __syncthreads();
+            const F other = xch[8*v+0][wave^1][cl];
+            if (h == 1) pe *= other;
+            ptot *= other;
+        }
         const F dir_top = inc_dir.v[v] * mu.v[v];
         dir_in[v] = dir_top * pe;
-        const F dir_sfc = shfl(dir_top * pr, (LL-1)*CL + cl);
+        const F dir_sfc = dir_top * ptot;
         #pragma unroll
         for (int j=0; j<K; ++j)
         {
@@ -219,8 +252,22 @@ sw_2stream_scan_kernel(
                 m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
             }
         }
+        F x00 = F(1.), x01 = F(0.), x10 = F(0.);      // composite of everything below this wave's levels
+        if constexpr (W == 2)
+        {
+            if (ll == 0) { xch[8*v+1][wave][cl] = m00; xch[8*v+2][wave][cl] = m01; xch[8*v+3][wave][cl] = m10; }
+            __syncthreads();
+            if (h == 0)
+            {
+                x00 = xch[8*v+1][wave^1][cl]; x01 = xch[8*v+2][wave^1][cl]; x10 = xch[8*v+3][wave^1][cl];
+                const F n00 = m00*x00 + m01*x10, n01 = m00*x01 + m01;
+                const F n10 = m10*x00 + x10,     n11 = m10*x01 + F(1.);
+                const F inv = fast_rcp(n11);
+                m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
+            }
+        }
         F e00 = shfl(m00, lane + CL), e01 = shfl(m01, lane + CL), e10 = shfl(m10, lane + CL);
-        if (ll == LL-1) { e00 = F(1.); e01 = F(0.); e10 = F(0.); }
+        if (ll == LL-1) { e00 = x00; e01 = x01; e10 = x10; }
         const F alb_sfc = a_dif.v[v];
         F a = (e00*alb_sfc + e01) * fast_rcp(e10*alb_sfc + F(1.));      // albedo at the bottom of this lane's chunk
 
@@ -251,8 +298,19 @@ sw_2stream_scan_kernel(
             const F a2 = shfl(sa, lane + d*CL), b2 = shfl(sbb, lane + d*CL);
             if (ll + d < LL) { sbb = sa*b2 + sbb; sa = sa*a2; }
         }
+        F xa = F(1.), xb = F(0.);
+        if constexpr (W == 2)
+        {
+            if (ll == 0) { xch[8*v+4][wave][cl] = sa; xch[8*v+5][wave][cl] = sbb; }
+            __syncthreads();
+            if (h == 0)
+            {
+                xa = xch[8*v+4][wave^1][cl]; xb = xch[8*v+5][wave^1][cl];
+                sbb = sa*xb + sbb; sa = sa*xa;
+            }
+        }
         F ae = shfl(sa, lane + CL), be = shfl(sbb, lane + CL);
-        if (ll == LL-1) { ae = F(1.); be = F(0.); }
+        if (ll == LL-1) { ae = xa; be = xb; }
         const F src_sfc = dir_sfc * a_dir.v[v];
         F s = ae*src_sfc + be;                                   // src at the bottom of this lane's chunk
 
@@ -277,13 +335,24 @@ sw_2stream_scan_kernel(
             const F a2 = shfl(da, lane - d*CL), b2 = shfl(db, lane - d*CL);
             if (ll >= d) { db = da*b2 + db; da = da*a2; }
         }
+        xa = F(1.); xb = F(0.);
+        if constexpr (W == 2)
+        {
+            if (ll == LL-1) { xch[8*v+6][wave][cl] = da; xch[8*v+7][wave][cl] = db; }
+            __syncthreads();
+            if (h == 1)
+            {
+                xa = xch[8*v+6][wave^1][cl]; xb = xch[8*v+7][wave^1][cl];
+                db = da*xb + db; da = da*xa;
+            }
+        }
         ae = shfl(da, lane - CL); be = shfl(db, lane - CL);
-        if (ll == 0) { ae = F(1.); be = F(0.); }
+        if (ll == 0) { ae = xa; be = xb; }
         const F dn_top = (inc_flux_dif != nullptr) ? inc_dif.v[v] : F(0.);
         dn_in[v] = ae*dn_top + be;
     }
 
-    if (!active) return;
+    if (!active || wave_col0 >= ncol) return;
 
     // ---- replay the diffuse downward flux and store this lane's K levels as soon as each value exists
     F dn[V];
@@ -413,18 +482,19 @@ int g_sync_waves = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
 
 extern int g_sync_waves;
 
-template<typename F, int V>
+template<typename F, int V, int W>
 bool launch_scan(hipStream_t st,
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
-    const dim3 grid(ceil_div(ncol, 4*CL*V), ngpt);
-    const int need = ceil_div(nlay+1, LL);
-#define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK><<<grid, 256, 0, st>>>( \
+    const dim3 grid(ceil_div(ncol, (4/W)*CL*V), ngpt);
+    const int need = ceil_div(nlay+1, LL*W);
+#define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK,W><<<grid, 256, 0, st>>>( \
         ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
         flux_up, flux_dn, flux_dir, g_sync_waves); return true; }
-    RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33)
+    if constexpr (W == 1) { RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33) }
+    else                  { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6)  RRX_SW_K(9)  RRX_SW_K(12) RRX_SW_K(17) }
 #undef RRX_SW_K
     return false;
 }
@@ -455,18 +525,21 @@ int sw_solver_2stream_impl(
         up = ws; dn = ws + nlevcol*ngpt; dr = ws + 2*nlevcol*ngpt;
     }
 
+    // g_sw_variant: 0 = default (two-wave level split), 1 = serial fallback, 2 = one wave per column group, 3 = two waves
     bool done = false;
     if (g_sw_variant != 1)
     {
+#define RRX_SW_ARGS st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, dif, up, dn, dr
+        const bool two = (g_sw_variant != 2);
         if constexpr (sizeof(F) == 4)
         {
-            if (ncol % 2 == 0)
-                done = launch_scan<F,2>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                    inc_flux_dir, dif, up, dn, dr);
+            if (g_sw_variant == 4 && ncol % 4 == 0) done = launch_scan<F,4,2>(RRX_SW_ARGS);
+            else if (ncol % 2 == 0)
+                done = two ? launch_scan<F,2,2>(RRX_SW_ARGS) : launch_scan<F,2,1>(RRX_SW_ARGS);
         }
         if (!done)
-            done = launch_scan<F,1>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                    inc_flux_dir, dif, up, dn, dr);
+            done = two ? launch_scan<F,1,2>(RRX_SW_ARGS) : launch_scan<F,1,1>(RRX_SW_ARGS);
+#undef RRX_SW_ARGS
     }
     if (!done)
     {
