@@ -68,6 +68,31 @@ namespace Gas_optics_rrtmgp_kernels_cuda
                  jeta, jtemp, jpress, tau);
     }
 
+    inline void compute_tau_absorption_set(
+            const int ncol, const int nlay, const int nband, const int ngpt,
+            const int ngas, const int nflav, const int neta, const int npres, const int ntemp,
+            const int nminorlower, const int nminorklower, const int nminorupper, const int nminorkupper,
+            const int idx_h2o, const int* gpoint_flavor, const int* band_lims_gpt,
+            const Float* kmajor, const Float* kminor_lower, const Float* kminor_upper,
+            const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+            const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+            const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+            const int* idx_minor_lower, const int* idx_minor_upper,
+            const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper,
+            const int* kminor_start_lower, const int* kminor_start_upper,
+            const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
+            const Float* play, const Float* tlay, const Float* col_gas,
+            const int* jeta, const int* jtemp, const int* jpress, Float* tau)
+    {
+        RRX_CALL(rrx_compute_tau_absorption_set, ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp,
+                 nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt,
+                 kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                 minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
+                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                 kminor_start_lower, kminor_start_upper, tropo, col_mix, fmajor, fminor, play, tlay, col_gas,
+                 jeta, jtemp, jpress, tau);
+    }
+
     inline void gas_optics_sw_fused(
             const int ncol, const int nlay, const int nband, const int ngpt,
             const int ngas, const int nflav, const int neta, const int npres, const int ntemp,

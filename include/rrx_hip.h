@@ -113,6 +113,22 @@ int rrx_compute_tau_absorption##SFX( \
         const RrxBool* tropo, const F* col_mix, const F* fmajor, const F* fminor, \
         const F* play, const F* tlay, const F* col_gas, \
         const int* jeta, const int* jtemp, const int* jpress, F* tau, void* stream); \
+/* addition: the same sum STORED into tau (what Gas_optics_rrtmgp_gpu needs after its zero fill: src_cuda/Gas_optics_rrtmgp.cu \
+   compute_gas_taus; saves the fill and the read-back) */ \
+int rrx_compute_tau_absorption_set##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const RrxBool* tropo, const F* col_mix, const F* fmajor, const F* fminor, \
+        const F* play, const F* tlay, const F* col_gas, \
+        const int* jeta, const int* jtemp, const int* jpress, F* tau, void* stream); \
 /* compute_planck_source: launchers.cu:441-521 */ \
 int rrx_compute_planck_source##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \

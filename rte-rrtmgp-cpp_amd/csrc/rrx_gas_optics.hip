@@ -166,6 +166,7 @@ __device__ __forceinline__ Pair<F> ld2(const F* __restrict__ base, const unsigne
 
 // MODE 0: tau += major + minor            (compute_tau_absorption, reference semantics: caller zeroes tau)
 // MODE 1: tau/ssa/g = fused absorption + Rayleigh + combine   (SW gas optics in one pass)
+// MODE 2: tau  = major + minor            (LW gas optics without the zero fill and the read-back of MODE 0)
 // major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
 // minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
 // A minor interval uses the flavor of its first g-point, exactly as the reference kernel (:533).
@@ -397,6 +398,10 @@ tau_absorption_kernel(
                 if constexpr (MODE == 0)
                 {
                     tau[o] = told[u] + t[u];
+                }
+                else if constexpr (MODE == 2)
+                {
+                    tau[o] = t[u];
                 }
                 else
                 {
@@ -780,6 +785,29 @@ int rrx_compute_tau_absorption##SFX( \
             idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
             tropo, col_mix, fmajor, fminor, play, tlay, col_gas, (const F*)nullptr, jeta, jtemp, jpress, (const F*)nullptr, \
             tau, (F*)nullptr, (F*)nullptr, stream, "rrx_compute_tau_absorption"); \
+} \
+int rrx_compute_tau_absorption_set##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const RrxBool* tropo, const F* col_mix, const F* fmajor, const F* fminor, \
+        const F* play, const F* tlay, const F* col_gas, \
+        const int* jeta, const int* jtemp, const int* jpress, F* tau, void* stream) \
+{ \
+    return tau_absorption_impl<F,2>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, (const F*)nullptr, jeta, jtemp, jpress, (const F*)nullptr, \
+            tau, (F*)nullptr, (F*)nullptr, stream, "rrx_compute_tau_absorption_set"); \
 } \
 int rrx_gas_optics_sw_fused##SFX( \
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \

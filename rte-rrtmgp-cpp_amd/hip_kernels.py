@@ -178,6 +178,12 @@ class HipKernels:
                 it["jeta"], it["jtemp"], it["jpress"], tau)
         return tau
 
+    def compute_tau_absorption_set(self, kd, it, play, tlay, col_gas, tau):
+        """tau = major + minor (no zero fill, no read-back); same arithmetic as compute_tau_absorption on a zeroed tau"""
+        self._c("compute_tau_absorption_set", *self._absorption_args(kd, it, play, tlay, col_gas),
+                it["jeta"], it["jtemp"], it["jpress"], tau)
+        return tau
+
     def gas_optics_sw_fused(self, kd, it, play, tlay, col_gas, col_dry, tau, ssa, g):
         self._c("gas_optics_sw_fused", *self._absorption_args(kd, it, play, tlay, col_gas), col_dry,
                 it["jeta"], it["jtemp"], it["jpress"], kd.krayl, tau, ssa, g)

@@ -449,8 +449,8 @@ void Gas_optics_rrtmgp_gpu::compute_gas_taus(
     }
     else
     {
-        Gas_optics_rrtmgp_kernels_cuda::zero_array(ncol, nlay, ngpt, optical_props->get_tau().ptr());
-        Gas_optics_rrtmgp_kernels_cuda::compute_tau_absorption(
+        // tau = major + minor in one pass (the reference zero-fills tau and adds onto it: same values)
+        Gas_optics_rrtmgp_kernels_cuda::compute_tau_absorption_set(
                 ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp,
                 nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o,
                 gpoint_flavor_gpu.ptr(), band_lims, kmajor_gpu.ptr(), kminor_lower_gpu.ptr(), kminor_upper_gpu.ptr(),

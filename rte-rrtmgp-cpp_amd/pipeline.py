@@ -60,8 +60,11 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
     col_dry, col_gas, it = gas_state(be, kd, atm, col_dry)
 
-    tau = be.zeros((ngpt, nlay, ncol))
-    be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
+    if hasattr(be, "compute_tau_absorption_set"):
+        tau = be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
+    else:
+        tau = be.zeros((ngpt, nlay, ncol))
+        be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
     src = be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm))
 
     if cloud_lut is not None:
@@ -207,8 +210,7 @@ class ResidentSolver:
             col_gas = be.fill_gases(kd, atm.vmr, col_dry)
             it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
             if kind == "lw":
-                buf["tau"].zero_()
-                be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
                 mark("lw_gas_optics", True)
                 mark("lw_planck")
                 be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm),

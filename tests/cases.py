@@ -57,6 +57,10 @@ class Checker:
         g = self.be.to_numpy(got)
         assert np.array_equal(g.astype(np.int64), np.asarray(want).astype(np.int64)), f"{name}: integer mismatch ({self.be.name})"
 
+    def same_bits(self, name, got, want):
+        g = self.be.to_numpy(got); w = self.be.to_numpy(want)
+        assert g.dtype == w.dtype and np.array_equal(g.view(np.uint8), w.view(np.uint8)), f"{name}: not bit-identical ({self.be.name})"
+
 
 def dtype_of(G):
     return G["lw_tau"].dtype
@@ -91,6 +95,9 @@ def run_chain_case(be, G, tol):
             tau = be.zeros((kd.ngpt, nlay, ncol))
             be.compute_tau_absorption(kd, it, play, tlay, col_gas, tau)
             ck.close("lw_tau", tau, G["lw_tau"])
+            if hasattr(be, "compute_tau_absorption_set"):       # store form == add form on a zeroed tau, bit for bit
+                t2 = be.compute_tau_absorption_set(kd, it, play, tlay, col_gas, be.empty(tau.shape))
+                ck.same_bits("lw_tau_set", t2, tau)
             src = be.compute_planck_source(kd, it, tlay, tlev, tsfc, nlay if top_at_1 else 1)
             for k in ("lay_src", "lev_src", "sfc_src", "sfc_src_jac"):
                 ck.close("lw_" + k, src[k], G["lw_" + k])

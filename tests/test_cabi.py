@@ -26,7 +26,7 @@ def test_header_declares_the_reference_launcher_surface():
     # the 5 reference launcher namespaces (include_kernels_cuda/*.h) must all be covered
     for must in ("rrx_lw_solver_noscat_f64", "rrx_sw_solver_2stream_f64", "rrx_lw_secants_array_f64",
                  "rrx_apply_BC_0_f64", "rrx_apply_BC_gpt_f64", "rrx_apply_BC_factor_f64",
-                 "rrx_interpolation_f64", "rrx_compute_tau_absorption_f64", "rrx_compute_tau_rayleigh_f64",
+                 "rrx_interpolation_f64", "rrx_compute_tau_absorption_f64", "rrx_compute_tau_absorption_set_f64", "rrx_compute_tau_rayleigh_f64",
                  "rrx_combine_abs_and_rayleigh_f64", "rrx_compute_planck_source_f64", "rrx_reorder123x321_f64",
                  "rrx_reorder12x21_f64", "rrx_zero_array_f64",
                  "rrx_increment_1scalar_by_1scalar_f64", "rrx_increment_2stream_by_2stream_f64",
