@@ -25,8 +25,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic words per (column, g-point) at nlay layers -- SURVEY.md section 8(d), DESIGN.md section 5
-def algo_words(nlay):
+def algo_words(nlay, ngpt, broadband):
     nlev = nlay + 1
+    if broadband:       # fused form: the solvers keep the g-point sums on chip and store (ncol, nlev) arrays once
+        return dict(
+            lw_gas_optics=nlay,
+            lw_planck=2*nlay + 1 + 2,
+            lw_solver=3*nlay + 1 + 2 + 2*nlev/ngpt,
+            lw_reduce=0,
+            sw_gas_optics=3*nlay + 1,
+            sw_solver=3*nlay + 3 + 3*nlev/ngpt,
+            sw_reduce=0)
     return dict(
         lw_gas_optics=nlay,                              # tau
         lw_planck=2*nlay + 1 + 2,                        # lay_src, lev_src, sfc_src(+jac)
@@ -71,13 +80,18 @@ def main():
     ap.add_argument("--nlay", type=int, default=140)
     ap.add_argument("--ngpt", type=int, default=256)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--broadband", action="store_true", help="fuse the g-point sum into the solvers (CPU-path semantics)")
+    ap.add_argument("--flux-mode", default="broadband", choices=["broadband", "per-gpoint"],
+                    help="broadband: do_broadband solvers, g-point sums kept on chip (the CPU path's semantics, default); "
+                         "per-gpoint: per-g-point fluxes stored, then sum_broadband (the reference GPU path's flow)")
+    ap.add_argument("--broadband", action="store_true", help="same as --flux-mode broadband")
+    ap.add_argument("--per-gpoint", action="store_true", help="same as --flux-mode per-gpoint")
     ap.add_argument("--lw-variant", type=int, default=0)
     ap.add_argument("--sw-variant", type=int, default=0)
     ap.add_argument("--cpu-cols", type=int, default=6000, help="columns of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
     args = ap.parse_args()
+    args.broadband = (args.flux_mode == "broadband" or args.broadband) and not args.per_gpoint
 
     import torch
     import torch.distributed as dist
@@ -137,11 +151,11 @@ def main():
     if rank == 0:
         S = np_dtype().itemsize
         ms = solver.stage_ms()
-        words = algo_words(args.nlay)
+        words = algo_words(args.nlay, args.ngpt, args.broadband)
         units = args.ncol * args.ngpt
         kernels = {}
         for st, w in words.items():
-            gbs = w * units * S / (ms[st]*1e-3) / 1e9
+            gbs = w * units * S / (max(ms[st], 1e-6)*1e-3) / 1e9
             kernels[st] = dict(ms=round(ms[st], 4), algo_GB=round(w*units*S/1e9, 4), GBs=round(gbs, 1), frac=round(gbs/HBM_PEAK_GBS, 4))
         single = {k: v for k, v in kernels.items() if k in ("lw_solver", "sw_solver", "lw_planck")}   # single-launch stages
         dom = max(single, key=lambda k: single[k]["ms"])
@@ -157,7 +171,8 @@ def main():
             "config": {"workload": f"C4 synthetic {args.ncol} columns/GPU x {args.nlay} layers x {args.ngpt} g-points, "
                                    f"LW+SW clear-sky, RCEMIP profile, synthetic k-distribution (real shapes)",
                        "columns_per_gpu": args.ncol, "nlay": args.nlay, "ngpt": args.ngpt,
-                       "flux_mode": "broadband-fused" if args.broadband else "per-g-point + sum_broadband",
+                       "flux_mode": "broadband (do_broadband solvers, g-point sums on chip)" if args.broadband
+                                    else "per-g-point fluxes + sum_broadband",
                        "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac"], "traffic": None,

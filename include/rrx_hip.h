@@ -51,6 +51,9 @@ int rrx_subset_nd(void* out, const void* in, int elem_bytes, int ndim, const int
 /* kernel-variant switches used by bench.py A/B runs (0 = default) */
 int rrx_set_lw_variant(int v);
 int rrx_set_sw_variant(int v);
+/* column groups (8 or 16 columns x all levels) below which do_broadband falls back from the fused one-kernel form to
+   per-g-point fluxes in a workspace + sum (default 1024; 1 = always fused) */
+int rrx_set_broadband_min_groups(int n);
 
 #define RRX_DECLARE(F, SFX) \
 /* ---- Rte_solver_kernels_cuda : include_kernels_cuda/rte_solver_kernels_cuda.h:33-64 ---- */ \

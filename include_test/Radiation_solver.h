@@ -63,7 +63,7 @@ class Radiation_solver_longwave
         std::unique_ptr<Cloud_optics_gpu> cloud_optics_gpu;
         Rte_lw_gpu rte_lw;
         int n_col_block = 16384;
-        bool broadband_solvers = false;
+        bool broadband_solvers = true;
 
         struct Workspace;
         std::shared_ptr<Workspace> ws_block, ws_residual;
@@ -119,7 +119,7 @@ class Radiation_solver_shortwave
         std::unique_ptr<Cloud_optics_gpu> cloud_optics_gpu;
         Rte_sw_gpu rte_sw;
         int n_col_block = 16384;
-        bool broadband_solvers = false;
+        bool broadband_solvers = true;
 
         struct Workspace;
         std::shared_ptr<Workspace> ws_block, ws_residual;

@@ -11,6 +11,8 @@ typedef signed char Bool;   // RTE_USE_CBOOL in every shipped reference config (
 
 namespace rrx
 {
+extern int g_bb_min_groups;     // defined in rrx_solver_sw.hip; set through rrx_set_broadband_min_groups
+
     // ---- error plumbing: C-ABI functions return int, message retrievable with rrx_last_error() ----
     void set_error(const std::string& msg);
     int check_launch(const char* what);
@@ -69,6 +71,15 @@ namespace rrx
             for (int i=0; i<V; ++i) t[i] = r.v[i];
             *reinterpret_cast<vecT*>(p) = t;
         }
+    }
+
+    // acc += x as a separate rounded addition: never fused with the multiplication that produced x, whatever the
+    // contraction mode of the calling file (the fused broadband sums must round like sum_broadband on stored fluxes)
+    template<typename F>
+    __device__ __forceinline__ void add_rounded(F& acc, const F x)
+    {
+        #pragma clang fp contract(off)
+        acc = acc + x;
     }
 
     // 1/x to ~1 ulp without the IEEE corner-case handling of a full division (operands here are finite, normal and

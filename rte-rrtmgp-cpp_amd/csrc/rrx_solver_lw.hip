@@ -31,7 +31,10 @@ constexpr int LL = 8;    // level lanes
 // W = waves per column group: 1 = the whole column in one wavefront (8 level-lanes x K layers); 2 = the levels of the
 // same 8*V columns spread over 16 level-lanes in two adjacent wavefronts (half the per-lane state, twice the resident
 // waves); the two vertical scans then exchange each wave's total through LDS, one block barrier per scan.
-template<typename F, int V, int K, int W, bool JAC, bool ACC>
+// BB (broadband): the workgroup walks over ALL g-points of its columns and keeps the g-point sum of both fluxes in
+// registers (same summation order as sum_broadband over stored per-g-point fluxes, so the same bits); flux_up/flux_dn
+// are then (ncol, nlev) arrays. Saves the per-g-point flux stores and the reduction pass that reads them back.
+template<typename F, int V, int K, int W, bool JAC, bool ACC, bool BB = false>
 __global__ void __launch_bounds__(256, (W == 2) ? 2 : 1)
 lw_noscat_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
@@ -45,22 +48,37 @@ lw_noscat_scan_kernel(
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
-    const int igpt = blockIdx.y;
     const int h = (W == 2) ? (wave & 1) : 0;         // which half of the column this wave holds (0 = TOA side)
     const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
     __shared__ F xch[(W == 2) ? 4*V : 1][4][CL];     // wave totals of the two scans
     // The two waves that share each 128-B line (8 columns x 8 B = 64 B per wave when V = 1) must issue their load
     // bursts together, or the second half of every line is fetched from HBM again once L2 has turned over
     // (measured: +26 % FETCH_SIZE without the barrier). No thread leaves before the barrier.
-    if (sync_waves) __syncthreads();
     if constexpr (W == 1) { if (wave_col0 >= ncol) return; }   // wave-uniform; W == 2 keeps every wave for the barriers
 
     int icol = wave_col0 + cl*V;
     const bool active = icol < ncol;                  // all V columns exist (ncol % V == 0) or none
     if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;    // harmless duplicate loads, no stores
+    const bool writer = active && wave_col0 < ncol;
 
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
+    const int t0 = (h*LL + ll)*K;
+
+    F acc_up[BB ? K : 1][V], acc_dn[BB ? K : 1][V];
+    if constexpr (BB)
+    {
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+            #pragma unroll
+            for (int v=0; v<V; ++v) { acc_up[j][v] = F(0.); acc_dn[j][v] = F(0.); }
+    }
+
+    const int g_begin = BB ? 0 : blockIdx.y;
+    const int g_end = BB ? ngpt : blockIdx.y + 1;
+    for (int igpt=g_begin; igpt<g_end; ++igpt)
+    {
+    if (sync_waves) __syncthreads();
     const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
     const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
     const size_t sfc_idx = size_t(igpt)*ncl + icol;
@@ -71,8 +89,6 @@ lw_noscat_scan_kernel(
 
     const Vec<F,V> D = load_cols<F,V>(secants + sfc_idx + size_t(imu)*ncl*ngpt);
     const F w = weights[imu];
-
-    const int t0 = (h*LL + ll)*K;
 
     F tr[K][V], sdn[K][V], sup[K][V];
     Vec<F,V> lv[K];
@@ -206,13 +222,12 @@ lw_noscat_scan_kernel(
     }
 
     // ---- replay this lane's K layers and store its K levels (each value is stored as soon as it exists: no staging)
-    if (!active || wave_col0 >= ncol) return;
     const F scale = pi * w;
 
     auto put = [&](F* __restrict__ arr, const int j, Vec<F,V> val)
     {
         const int t = t0 + j;
-        if (t <= nlay)
+        if (writer && t <= nlay)
         {
             const int ml = top_at_1 ? t : nlay - t;
             F* o = arr + lev_base + size_t(ml)*ncl;
@@ -236,7 +251,12 @@ lw_noscat_scan_kernel(
             Vec<F,V> o;
             #pragma unroll
             for (int v=0; v<V; ++v) { o.v[v] = scale * dn[v]; dn[v] = tr[j][v]*dn[v] + sdn[j][v]; }
-            put(flux_dn, j, o);
+            if constexpr (BB)
+            {
+                #pragma unroll
+                for (int v=0; v<V; ++v) add_rounded(acc_dn[j][v], o.v[v]);
+            }
+            else put(flux_dn, j, o);
         }
     }
     {
@@ -254,8 +274,34 @@ lw_noscat_scan_kernel(
                 o.v[v] = scale * up[v];
                 if constexpr (JAC) { jc[v] = tr[j][v]*jc[v]; oj.v[v] = scale * jc[v]; }
             }
-            put(flux_up, j, o);
+            if constexpr (BB)
+            {
+                #pragma unroll
+                for (int v=0; v<V; ++v) add_rounded(acc_up[j][v], o.v[v]);
+            }
+            else put(flux_up, j, o);
             if constexpr (JAC) put(flux_up_jac, j, oj);
+        }
+    }
+    }   // g-point loop
+
+    if constexpr (BB)
+    {
+        if (!writer) return;
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            const int t = t0 + j;
+            if (t <= nlay)
+            {
+                const int ml = top_at_1 ? t : nlay - t;
+                const size_t o = size_t(icol) + size_t(ml)*ncl;
+                Vec<F,V> u, d;
+                #pragma unroll
+                for (int v=0; v<V; ++v) { u.v[v] = acc_up[j][v]; d.v[v] = acc_dn[j][v]; }
+                store_cols<F,V>(flux_up + o, u);
+                store_cols<F,V>(flux_dn + o, d);
+            }
         }
     }
 }
@@ -403,7 +449,25 @@ bool launch_scan(
 }
 
 // 0 = default, 1 = serial fallback, 2 = one wave/V=1, 3 = one wave/wide rows, 4 = two waves/64-B rows,
-// 5 = two waves/128-B rows, 6 = one wave/64-B rows
+// 5 = two waves/128-B rows, 6 = one wave/64-B rows, 7 = default kernels but never the fused broadband form
+// fused broadband form: one workgroup walks all g-points of its columns (grid.y = 1)
+template<typename F, int V, int W>
+bool launch_scan_bb(
+        hipStream_t st, const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
+{
+    const dim3 grid(ceil_div(ncol, (4/W)*CL*V), 1);
+    const int need = ceil_div(nlay+1, LL*W);
+    const int imu = 0;
+    const F* sfc_src_jac = nullptr; F* flux_up_jac = nullptr;
+#define RRX_LW_K(KK) if (need <= KK) { lw_noscat_scan_kernel<F,V,KK,W,false,false,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS); return true; }
+    if constexpr (W == 1) { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) }
+    else                  { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) }
+#undef RRX_LW_K
+    return false;
+}
+
 int g_lw_variant = 0;
 
 #define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
@@ -426,7 +490,19 @@ int lw_solver_noscat_impl(
     if (nmus < 1 || nmus > 4) throw std::runtime_error("n_quad_angs must be 1..4");
     const bool jac = do_jacobians && sfc_src_jac != nullptr && flux_up_jac != nullptr;
 
-    // broadband mode: per-g-point fluxes go to a workspace, then are summed over g-points
+    // broadband mode, fused form: g-point sums kept in registers, no per-g-point fluxes in memory. Taken when there are
+    // enough column groups to fill the chip without splitting the g-point range (which keeps sum_broadband's order).
+    constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+    if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && ncol % VBB == 0
+        && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
+    {
+        if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
+        if (launch_scan_bb<F,VBB,2>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                    sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
+            return 0;
+    }
+
+    // broadband mode, general form: per-g-point fluxes go to a workspace, then are summed over g-points
     F* up = flux_up; F* dn = flux_dn;
     F* ws = nullptr;
     const size_t nlevcol = size_t(ncol)*(nlay+1);

@@ -17,13 +17,28 @@
 
 #pragma clang fp contract(fast)
 
+namespace rrx
+{
+// column groups (8*V columns x all levels) needed before the solvers take the fused broadband form: below that the
+// groups alone do not fill the chip and splitting the g-point range would change the summation order
+int g_bb_min_groups = 1024;
+}
+
 namespace
 {
 using namespace rrx;
 
 constexpr int CL = 8;
 constexpr int LL = 8;
-constexpr int LOADG = 6;   // layers per load group   // layers per load group
+constexpr int LOADG = 6;   // layers per load group
+#ifndef RRX_SW_BB_LOADS
+#define RRX_SW_BB_LOADS 3
+#endif
+#ifndef RRX_SW_BB_EVALS
+#define RRX_SW_BB_EVALS 2
+#endif
+constexpr int BB_LOADS = RRX_SW_BB_LOADS;   // fused broadband form: layers of loads in flight ahead of the evaluation
+constexpr int BB_EVALS = RRX_SW_BB_EVALS;   // fused broadband form: two_stream evaluations the scheduler may interleave
 #ifndef RRX_SW_MINWAVES
 #define RRX_SW_MINWAVES 1
 #endif
@@ -88,7 +103,10 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // W = waves per column group: W = 1 keeps the whole column in one wavefront (8 level-lanes); W = 2 spreads the levels of
 // 8*V columns over 16 level-lanes in two adjacent wavefronts (half the per-lane state, so more resident waves per
 // SIMD); the four vertical scans then exchange each wave's total through LDS with one block barrier per scan.
-template<typename F, int V, int K, int W>
+// BB (broadband): the workgroup walks over ALL g-points of its columns and keeps the g-point sums of the three fluxes
+// on chip (up and dn in LDS, dir in registers), added in g-point order like sum_broadband does on stored per-g-point
+// fluxes, so the same bits; flux_up/dn/dir are then (ncol, nlev) arrays.
+template<typename F, int V, int K, int W, bool BB = false>
 __global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
@@ -102,17 +120,16 @@ sw_2stream_scan_kernel(
     __shared__ F lds_alb[K*V][256];
     __shared__ F lds_dir[K*V][256];
     __shared__ F xch[(W == 2) ? 8*V : 1][4][CL];    // wave totals of the scans (one slot per scan component)
+    __shared__ F lds_acc_up[BB ? K*V : 1][256];
+    __shared__ F lds_acc_dn[BB ? K*V : 1][256];
 
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
-    const int igpt = blockIdx.y;
     const int h = (W == 2) ? (wave & 1) : 0;          // which half of the column this wave holds (0 = TOA side)
     const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
-    // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip)
-    if (sync_waves) __syncthreads();
     if constexpr (W == 1) { if (wave_col0 >= ncol) return; }
 
     // W == 2: every wave stays alive until the last barrier; lanes without a column compute on a clamped one
@@ -120,17 +137,34 @@ sw_2stream_scan_kernel(
     const bool active = icol < ncol;
     if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;
 
+    const bool writer = active && wave_col0 < ncol;
     const int nlev = nlay + 1;
     const size_t ncl = size_t(ncol);
-    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
-    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
-    const size_t sfc_idx = size_t(igpt)*ncl + icol;
     const int t0 = (h*LL + ll)*K;
 
     const Vec<F,V> mu = load_cols<F,V>(mu0 + icol);
     F mu_inv[V];
     #pragma unroll
     for (int v=0; v<V; ++v) mu_inv[v] = F(1.)/mu.v[v];
+
+    F acc_dir[BB ? K : 1][V];
+    if constexpr (BB)
+    {
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+            #pragma unroll
+            for (int v=0; v<V; ++v) { acc_dir[j][v] = F(0.); lds_acc_up[j*V+v][tid] = F(0.); lds_acc_dn[j*V+v][tid] = F(0.); }
+    }
+
+    const int g_begin = BB ? 0 : blockIdx.y;
+    const int g_end = BB ? ngpt : blockIdx.y + 1;
+    for (int igpt=g_begin; igpt<g_end; ++igpt)
+    {
+    // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip)
+    if (sync_waves) __syncthreads();
+    const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
+    const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
+    const size_t sfc_idx = size_t(igpt)*ncl + icol;
 
     // per-layer state; names follow their LAST meaning
     F rp[K][V];      // r_dif            -> p = r_dif*denom
@@ -149,12 +183,32 @@ sw_2stream_scan_kernel(
         const bool valid = s < nlay;
         const int sc = min(s, nlay-1);
         const int ml = top_at_1 ? sc : nlay-1-sc;
-        const Vec<F,V> tv = load_cols<F,V>(tau + lay_base + size_t(ml)*ncl);
-        const Vec<F,V> wv = load_cols<F,V>(ssa + lay_base + size_t(ml)*ncl);
-        const Vec<F,V> gv = load_cols<F,V>(g   + lay_base + size_t(ml)*ncl);
+        size_t off = lay_base + size_t(ml)*ncl;
+        // Fused broadband form only (register budget: the g-point sums live across the whole body): empty asm statements
+        // tie this layer's loads to the result of layer j-BB_LOADS and each evaluation to the result BB_EVALS evaluations back,
+        // so that at most that many layers of loads / two_stream temporaries are live at once. The per-g-point form
+        // leaves the scheduler free (measured: 6.9 ms free vs 8.5 ms chained at 16384x140x224; fused 6.7 vs 14.7 ms).
+        if constexpr (BB)
+        {
+            if (j >= BB_LOADS) asm volatile("" : "+v"(off) : "v"(qb[j-BB_LOADS][V-1]));
+        }
+        Vec<F,V> tv = load_cols<F,V>(tau + off);
+        const Vec<F,V> wv = load_cols<F,V>(ssa + off);
+        const Vec<F,V> gv = load_cols<F,V>(g   + off);
+        // (V == 1: the tie sits ahead of the evaluation loop, V > 1: on each column's tau. Same dependence, but the
+        //  register allocator lands differently: measured fp64 6.3 vs 8.3 ms and fp32 6.4 vs 4.4 ms, tools/ab_sw.sh)
+        if constexpr (BB && V == 1)
+        {
+            if (j >= BB_EVALS) asm volatile("" : "+v"(tv.v[0]) : "v"(qb[j-BB_EVALS][0]));
+        }
         #pragma unroll
         for (int v=0; v<V; ++v)
         {
+            if constexpr (BB && V > 1)
+            {
+                const int e = j*V + v - BB_EVALS;             // the evaluation this one waits for
+                if (e >= 0) asm volatile("" : "+v"(tv.v[v]) : "v"(qb[e / V][e % V]));
+            }
             const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
             rp[j][v] = valid ? ts.r_dif : F(0.);
             al[j][v] = valid ? ts.t_dif : F(1.);
@@ -352,8 +406,6 @@ sw_2stream_scan_kernel(
         dn_in[v] = ae*dn_top + be;
     }
 
-    if (!active || wave_col0 >= ncol) return;
-
     // ---- replay the diffuse downward flux and store this lane's K levels as soon as each value exists
     F dn[V];
     #pragma unroll
@@ -372,13 +424,45 @@ sw_2stream_scan_kernel(
             dn[v] = al[j][v]*dn[v] + qb[j][v];
         }
         const int t = t0 + j;
-        if (t <= nlay)
+        if constexpr (BB)
+        {
+            #pragma unroll
+            for (int v=0; v<V; ++v)
+            {
+                F au = lds_acc_up[j*V+v][tid], ad = lds_acc_dn[j*V+v][tid];
+                add_rounded(au, ou.v[v]); add_rounded(ad, od.v[v]); add_rounded(acc_dir[j][v], odr.v[v]);
+                lds_acc_up[j*V+v][tid] = au; lds_acc_dn[j*V+v][tid] = ad;
+            }
+        }
+        else if (writer && t <= nlay)
         {
             const int ml = top_at_1 ? t : nlay - t;
             const size_t o = lev_base + size_t(ml)*ncl;
             store_cols<F,V>(flux_up + o, ou);
             store_cols<F,V>(flux_dn + o, od);
             store_cols<F,V>(flux_dir + o, odr);
+        }
+    }
+    }   // g-point loop
+
+    if constexpr (BB)
+    {
+        if (!writer) return;
+        #pragma unroll
+        for (int j=0; j<K; ++j)
+        {
+            const int t = t0 + j;
+            if (t <= nlay)
+            {
+                const int ml = top_at_1 ? t : nlay - t;
+                const size_t o = size_t(icol) + size_t(ml)*ncl;
+                Vec<F,V> u, d, r;
+                #pragma unroll
+                for (int v=0; v<V; ++v) { u.v[v] = lds_acc_up[j*V+v][tid]; d.v[v] = lds_acc_dn[j*V+v][tid]; r.v[v] = acc_dir[j][v]; }
+                store_cols<F,V>(flux_up + o, u);
+                store_cols<F,V>(flux_dn + o, d);
+                store_cols<F,V>(flux_dir + o, r);
+            }
         }
     }
 }
@@ -499,6 +583,22 @@ bool launch_scan(hipStream_t st,
     return false;
 }
 
+template<typename F, int V>
+bool launch_scan_bb(hipStream_t st,
+        const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
+        const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
+{
+    const dim3 grid(ceil_div(ncol, 2*CL*V), 1);
+    const int need = ceil_div(nlay+1, LL*2);
+#define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK,2,true><<<grid, 256, 0, st>>>( \
+        ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+        flux_up, flux_dn, flux_dir, g_sync_waves); return true; }
+    RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12)
+#undef RRX_SW_K
+    return false;
+}
+
 template<typename F>
 int sw_solver_2stream_impl(
         const int ncol, const int nlay, const int ngpt, const Bool top_at_1,
@@ -512,6 +612,17 @@ int sw_solver_2stream_impl(
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const F* dif = has_dif_bc ? inc_flux_dif : nullptr;
+
+    // broadband mode, fused form (see the kernel's BB note); taken when the column groups alone fill the chip
+    constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+    if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && ncol % VBB == 0 && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
+    {
+        if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
+            throw std::runtime_error("do_broadband needs flux_*_loc");
+        if (launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                  inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+            return 0;
+    }
 
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
     F* ws = nullptr;
@@ -578,6 +689,7 @@ int apply_BC_impl(int ncol, int nlay, int ngpt, Bool top_at_1, const F* inc, con
 extern "C"
 {
 int rrx_set_sw_variant(int v) { g_sw_variant = v; return 0; }
+int rrx_set_broadband_min_groups(int n) { g_bb_min_groups = n; return 0; }
 
 #define RRX_DEFINE_SW(F, SFX) \
 int rrx_sw_solver_2stream##SFX( \

@@ -332,6 +332,10 @@ class HipKernels:
         self._c("subset_cols", ncol_full, nrest, col_s, ncol_sub, arr, out)
         return out
 
+    def set_broadband_min_groups(self, n):
+        """column groups needed before do_broadband takes the fused one-kernel form (default 1024; 1 = always)"""
+        self.lib.call("rrx_set_broadband_min_groups", int(n))
+
     def set_variant(self, lw=None, sw=None):
         if lw is not None:
             self.lib.call("rrx_set_lw_variant", int(lw))

@@ -2,8 +2,8 @@
 // /root/reference/src_test/test_rte_rrtmgp.cu:196-818: read rte_rrtmgp_input, build the solvers from
 // coefficients_{lw,sw} (+ cloud_coefficients_*), upload, solve on the GPU (1 warm-up + 1 timed run, 10 more with
 // --timings), download, write rte_rrtmgp_output. Files are RRXB containers (include_test/Netcdf_interface.h), extension .nc
-// kept so that run scripts need no change; two extra options: --broadband-solvers (never materialise per-g-point
-// fluxes) and the environment variable RRX_COL_BLOCK (columns per block, default 16384).
+// kept so that run scripts need no change; two extra options: --broadband-solvers (on by default: the solvers sum the g-points
+// themselves; --no-broadband-solvers restores per-g-point fluxes + sum_broadband) and the environment variable RRX_COL_BLOCK (columns per block, default 16384).
 #include <chrono>
 #include <cstdlib>
 #include <iomanip>
@@ -93,7 +93,7 @@ void solve_radiation(int argc, char** argv)
         {"timings"          , { false, "Repeat computation 10x for run times."     }},
         {"delta-cloud"      , { true,  "delta-scaling of cloud optical properties"   }},
         {"delta-aerosol"    , { false, "delta-scaling of aerosol optical properties" }},
-        {"broadband-solvers", { false, "Sum g-points inside the solvers (no per-g-point fluxes)." }}};
+        {"broadband-solvers", { true,  "Sum g-points inside the solvers (no per-g-point fluxes; off with --output-bnd-fluxes)." }}};
 
     if (parse_command_line_options(command_line_options, argc, argv))
         return;
