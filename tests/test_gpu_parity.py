@@ -78,13 +78,21 @@ def test_full_solve_fp32_matches_fp32_oracle(kind, hip_f32, oracle_f32):
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
-def test_broadband_mode_equals_sum_of_gpoints(kind, hip_f64):
+@pytest.mark.parametrize("fused", [False, True], ids=["workspace", "fused"])
+@pytest.mark.parametrize("ncol,nlay,top_at_1", [(70, 60, False), (13, 33, True), (129, 140, False), (8, 16, True)])
+def test_broadband_mode_equals_sum_of_gpoints(kind, fused, ncol, nlay, top_at_1, hip_f64):
+    """do_broadband through the whole chain, in both of its forms (per-g-point fluxes in a workspace + sum, and the
+    fused kernels), on ragged column counts (partial wavefronts) and layer counts that pick different tilings."""
     h = []
-    for bb in (False, True):
-        r, _ = _solve_both(hip_f64, hip_f64, kind, 70, 60, False, False, do_broadband=bb)
-        h.append(r)
-    for k in ("flux_up", "flux_dn", "flux_net"):
-        assert cases.rel_err(h[1][k], h[0][k]) <= 1e-12
+    hip_f64.set_broadband_min_groups(1 if fused else 1 << 30)
+    try:
+        for bb in (False, True):
+            r, _ = _solve_both(hip_f64, hip_f64, kind, ncol, nlay, top_at_1, False, do_broadband=bb)
+            h.append(r)
+    finally:
+        hip_f64.set_broadband_min_groups(1024)
+    for k in ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ()):
+        assert cases.rel_err(h[1][k], h[0][k]) <= 1e-12, k
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
