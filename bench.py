@@ -48,6 +48,21 @@ def algo_words(nlay, ngpt, broadband):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def pmc_traffic(stage, args):
+    """HBM-side bytes per launch of the stage's kernel from the committed rocprofv3 counter summary of the SAME workload
+    (profiles/pmc_traffic.json, written by tools/profile_round.sh + tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no matching entry exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tag = f"{args.dtype}|{'broadband' if args.broadband else 'per-gpoint'}|{args.ncol}x{args.nlay}x{args.ngpt}|"
+    kern = {"lw_solver": "lw_noscat_scan_kernel", "sw_solver": "sw_2stream_scan_kernel", "lw_planck": "planck_source_kernel"}[stage]
+    for k, v in json.load(open(path)).items():
+        if k.startswith(tag + kern) and "fetch_bytes" in v and "write_bytes" in v:
+            return int(v["fetch_bytes"] + v["write_bytes"])
+    return None
+
+
 def cpu_baseline(args, kd_lw0, kd_sw0):
     """The oracle (scalar C++ port of the reference CPU path, oracle/rrtmgp_oracle.cpp) on a bounded sample of the
     same workload: `cpu_cols` columns in 12-column blocks like src_test/Radiation_solver.cpp:409, one thread."""
@@ -175,7 +190,7 @@ def main():
                                     else "per-g-point fluxes + sum_broadband",
                        "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["frac"], "traffic": None,
+                         "frac": kernels[dom]["frac"], "traffic": pmc_traffic(dom, args),
                          "algorithmic_bytes_per_launch": int(words[dom]*units*S), "avg_launch_ms": kernels[dom]["ms"]},
             "stages": kernels,
             "finite": finite,
