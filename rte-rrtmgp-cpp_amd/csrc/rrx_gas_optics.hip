@@ -195,12 +195,27 @@ tau_absorption_kernel(
     int* gflav = lds_int;                                   // [2][ngpt]
     int* gchg = lds_int + 2*ngpt;                           // [ngpt] 1 where the flavor of either regime changes
     int* lists = lds_int + 3*ngpt;
+    // per-contributor constants {idx_minor, scales_with_density, idx_minor_scaling, scale_by_complement} of both regimes:
+    // read from LDS in the chunk set-up, so that the per-cell scalings need no chain of dependent global loads
+    int* mmeta = lists + 2*nchunk*(1 + ITEM*nmax);           // [2][nmax][4]
     {
         const int tid = threadIdx.y*blockDim.x + threadIdx.x;
         for (int w = tid; w < 2*ngpt; w += blockDim.x*blockDim.y)
             gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
         for (int w = tid; w < ngpt; w += blockDim.x*blockDim.y)
             gchg[w] = (w > 0 && (gpoint_flavor[2*w] != gpoint_flavor[2*w-2] || gpoint_flavor[2*w+1] != gpoint_flavor[2*w-1])) ? 1 : 0;
+        for (int w = tid; w < nminorlower; w += blockDim.x*blockDim.y)
+        {
+            int* m = mmeta + 4*w;
+            m[0] = idx_minor_lower[w]; m[1] = minor_scales_with_density_lower[w] ? 1 : 0;
+            m[2] = idx_minor_scaling_lower[w]; m[3] = scale_by_complement_lower[w] ? 1 : 0;
+        }
+        for (int w = tid; w < nminorupper; w += blockDim.x*blockDim.y)
+        {
+            int* m = mmeta + 4*(nmax + w);
+            m[0] = idx_minor_upper[w]; m[1] = minor_scales_with_density_upper[w] ? 1 : 0;
+            m[2] = idx_minor_scaling_upper[w]; m[3] = scale_by_complement_upper[w] ? 1 : 0;
+        }
     }
     const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gpoint_flavor,
             nminorlower, minor_limits_gpt_lower, kminor_start_lower,
@@ -227,23 +242,23 @@ tau_absorption_kernel(
     F ray_fac = F(0.);
     if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
 
-    const Bool* swd = itropo == 0 ? minor_scales_with_density_lower : minor_scales_with_density_upper;
-    const Bool* sbc = itropo == 0 ? scale_by_complement_lower : scale_by_complement_upper;
-    const int* imn = itropo == 0 ? idx_minor_lower : idx_minor_upper;
-    const int* ims = itropo == 0 ? idx_minor_scaling_lower : idx_minor_scaling_upper;
-
+    // /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:505-529; both column amounts are requested at once
+    // (the scaling gas defaults to index 0 = col_dry where there is none: loaded, not used)
     auto minor_scaling = [&](const int imnr) -> F
     {
-        F scaling = col_gas[idx + size_t(imn[imnr])*ncl];
-        if (swd[imnr])
+        const int* m = mmeta + 4*(itropo*nmax + imnr);
+        const int imn = m[0], swd = m[1], ims = m[2], sbc = m[3];
+        F scaling = col_gas[idx + size_t(imn)*ncl];
+        const F cscal = col_gas[idx + size_t(max(ims, 0))*ncl];
+        if (swd)
         {
             scaling *= F(0.01) * pl / tl;
-            if (ims[imnr] > 0)
+            if (ims > 0)
             {
                 const F vmr_fact = F(1.) / cdry0;
                 const F dry_fact = F(1.) / (F(1.) + ch2o * vmr_fact);
-                const F x = col_gas[idx + size_t(ims[imnr])*ncl] * vmr_fact * dry_fact;
-                scaling *= sbc[imnr] ? (F(1.) - x) : x;
+                const F x = cscal * vmr_fact * dry_fact;
+                scaling *= sbc ? (F(1.) - x) : x;
             }
         }
         return scaling;
@@ -727,7 +742,7 @@ int tau_absorption_impl(
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = std::max(nminorlower, nminorupper);
-    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax))*sizeof(int);
+    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax) + size_t(8)*nmax)*sizeof(int);
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
