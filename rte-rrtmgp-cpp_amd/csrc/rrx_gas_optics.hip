@@ -137,6 +137,13 @@ __device__ inline MinorIndex build_minor_index(
     return mi;
 }
 
+#ifndef RRX_GO_NPRE
+#define RRX_GO_NPRE 1
+#endif
+#ifndef RRX_GO_NPRE32
+#define RRX_GO_NPRE32 1
+#endif
+constexpr int NPRE_F64 = RRX_GO_NPRE, NPRE_F32 = RRX_GO_NPRE32;   // minor contributors requested in the first batch of a g-point group
 constexpr int SL = 6;        // minor contributors of a chunk held in registers; further ones take a slower loop
 struct Slots { int lo[SL], hi[SL], koff[SL], mf[SL]; };
 
@@ -171,7 +178,7 @@ __device__ __forceinline__ Pair<F> ld2(const F* __restrict__ base, const unsigne
 // minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
 // A minor interval uses the flavor of its first g-point, exactly as the reference kernel (:533).
 template<typename F, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 tau_absorption_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
         const int nminorlower, const int nminorupper, const int idx_h2o,
@@ -302,6 +309,7 @@ tau_absorption_kernel(
     // G g-points at a time: all LUT gathers of the group are issued before the first use, so one memory round trip is
     // paid per group instead of per g-point (a g-point-at-a-time loop is latency-bound: 78 % of wave cycles in s_waitcnt).
     constexpr int G = 4;
+    constexpr int NPRE = (sizeof(F) == 8) ? NPRE_F64 : NPRE_F32;
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
     {
         int igs[G];
@@ -353,41 +361,57 @@ tau_absorption_kernel(
             for (int u=0; u<G; ++u) told[u] = tau[idx + size_t(igs[u])*ncl];
         }
 
+        const F* kmin = itropo == 0 ? kminor_lower : kminor_upper;
+        auto minor_active = [&](const int i) -> bool { return i < n && ig0 < sl.hi[i] && ig0 + G > sl.lo[i]; };
+        auto minor_load = [&](const int i, F (&mv)[G][4])
+        {
+            #pragma unroll
+            for (int u=0; u<G; ++u)
+            {
+                const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
+                const F* km = kmin + size_t(kg + sl.koff[i])*tn;
+                if (sl.mf[i] == cur_flav)
+                {
+                    const Pair<F> m0 = ld2(km, q0a), m1 = ld2(km, q0b);
+                    mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
+                    if (!same_eta) { mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                }
+                else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
+            }
+        };
+
+        // the first NPRE contributors of the chunk are requested together with the major / Rayleigh words: one memory
+        // round trip for the whole group where a g-point has at most NPRE contributors (the rule in the upper atmosphere)
+        F mvp[NPRE > 0 ? NPRE : 1][G][4];
+        #pragma unroll
+        for (int i=0; i<NPRE; ++i)
+            if (minor_active(i)) minor_load(i, mvp[i]);
+
         F t[G];
         #pragma unroll
         for (int u=0; u<G; ++u)
             t[u] = cm0 * (fm0*kv[u][0] + fm1*kv[u][1] + fm2*kv[u][2] + fm3*kv[u][3])
                  + cm1 * (fm4*kv[u][4] + fm5*kv[u][5] + fm6*kv[u][6] + fm7*kv[u][7]);
 
-        const F* kmin = itropo == 0 ? kminor_lower : kminor_upper;
-        #pragma unroll
-        for (int i=0; i<SL; ++i)
+        auto minor_accum = [&](const int i, const F (&mv)[G][4])
         {
-            if (i < n && ig0 < sl.hi[i] && ig0 + G > sl.lo[i])      // the contributor overlaps this group
+            #pragma unroll
+            for (int u=0; u<G; ++u)
             {
-                F mv[G][4];
-                #pragma unroll
-                for (int u=0; u<G; ++u)
+                if (igs[u] >= sl.lo[i] && igs[u] < sl.hi[i])
                 {
-                    const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
-                    const F* km = kmin + size_t(kg + sl.koff[i])*tn;
-                    if (sl.mf[i] == cur_flav)
-                    {
-                        const Pair<F> m0 = ld2(km, q0a), m1 = ld2(km, q0b);
-                        mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
-                        if (!same_eta) { mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
-                    }
-                    else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
+                    const F kk = (sl.mf[i] == cur_flav) ? fn0*mv[u][0] + fn1*mv[u][1] + fn2*mv[u][2] + fn3*mv[u][3] : mv[u][0];
+                    t[u] += kk * sc[i];
                 }
-                #pragma unroll
-                for (int u=0; u<G; ++u)
-                {
-                    if (igs[u] >= sl.lo[i] && igs[u] < sl.hi[i])
-                    {
-                        const F kk = (sl.mf[i] == cur_flav) ? fn0*mv[u][0] + fn1*mv[u][1] + fn2*mv[u][2] + fn3*mv[u][3] : mv[u][0];
-                        t[u] += kk * sc[i];
-                    }
-                }
+            }
+        };
+        #pragma unroll
+        for (int i=0; i<SL; ++i)                          // ascending contributor index: the reference's summation order
+        {
+            if (minor_active(i))
+            {
+                if (i < NPRE) minor_accum(i, mvp[i]);
+                else { F mv[G][4]; minor_load(i, mv); minor_accum(i, mv); }
             }
         }
         for (int i=SL; i<n; ++i)                          // more than SL contributors in one chunk: rare
