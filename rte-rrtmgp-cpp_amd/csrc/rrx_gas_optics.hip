@@ -106,10 +106,10 @@ struct MinorIndex
     __device__ __forceinline__ const int* item(int r, int c, int i) const { return base + r*stride_r + c*stride_c + 1 + ITEM*i; }
 };
 
+constexpr int MM = 8;        // ints per contributor in the LDS constant table
 __device__ inline MinorIndex build_minor_index(
-        int* lds, const int nchunk, const int nmax, const int* __restrict__ gpoint_flavor,
-        const int nminorlower, const int* __restrict__ lim_lower, const int* __restrict__ kst_lower,
-        const int nminorupper, const int* __restrict__ lim_upper, const int* __restrict__ kst_upper)
+        int* lds, const int nchunk, const int nmax, const int* gflav, const int ngpt,
+        const int* mmeta, const int nminorlower, const int nminorupper)
 {
     MinorIndex mi{lds, 1 + ITEM*nmax, nchunk*(1 + ITEM*nmax)};
     const int tid = threadIdx.y*blockDim.x + threadIdx.x;
@@ -118,17 +118,16 @@ __device__ inline MinorIndex build_minor_index(
     {
         const int r = w / nchunk, c = w % nchunk;
         const int n = r == 0 ? nminorlower : nminorupper;
-        const int* lim = r == 0 ? lim_lower : lim_upper;
-        const int* kst = r == 0 ? kst_lower : kst_upper;
         int* out = lds + r*mi.stride_r + c*mi.stride_c;
         int cnt = 0;
         for (int i=0; i<n; ++i)
         {
-            const int lo = lim[2*i]-1, hi = lim[2*i+1];          // [lo, hi) zero-based
+            const int* m = mmeta + MM*(r*nmax + i);
+            const int lo = m[4]-1, hi = m[5];                    // [lo, hi) zero-based
             if (lo < (c+1)*GCH && hi > c*GCH)
             {
                 int* it = out + 1 + ITEM*cnt;
-                it[0] = i; it[1] = lo; it[2] = hi; it[3] = kst[i]-1 - lo; it[4] = gpoint_flavor[2*lo + r] - 1;
+                it[0] = i; it[1] = lo; it[2] = hi; it[3] = m[6]-1 - lo; it[4] = gflav[r*ngpt + lo];
                 ++cnt;
             }
         }
@@ -204,7 +203,7 @@ tau_absorption_kernel(
     int* lists = lds_int + 3*ngpt;
     // per-contributor constants {idx_minor, scales_with_density, idx_minor_scaling, scale_by_complement} of both regimes:
     // read from LDS in the chunk set-up, so that the per-cell scalings need no chain of dependent global loads
-    int* mmeta = lists + 2*nchunk*(1 + ITEM*nmax);           // [2][nmax][4]
+    int* mmeta = lists + 2*nchunk*(1 + ITEM*nmax);           // [2][nmax][MM]: + {gpt_start, gpt_end, kminor_start}
     {
         const int tid = threadIdx.y*blockDim.x + threadIdx.x;
         for (int w = tid; w < 2*ngpt; w += blockDim.x*blockDim.y)
@@ -213,20 +212,21 @@ tau_absorption_kernel(
             gchg[w] = (w > 0 && (gpoint_flavor[2*w] != gpoint_flavor[2*w-2] || gpoint_flavor[2*w+1] != gpoint_flavor[2*w-1])) ? 1 : 0;
         for (int w = tid; w < nminorlower; w += blockDim.x*blockDim.y)
         {
-            int* m = mmeta + 4*w;
+            int* m = mmeta + MM*w;
             m[0] = idx_minor_lower[w]; m[1] = minor_scales_with_density_lower[w] ? 1 : 0;
             m[2] = idx_minor_scaling_lower[w]; m[3] = scale_by_complement_lower[w] ? 1 : 0;
+            m[4] = minor_limits_gpt_lower[2*w]; m[5] = minor_limits_gpt_lower[2*w+1]; m[6] = kminor_start_lower[w];
         }
         for (int w = tid; w < nminorupper; w += blockDim.x*blockDim.y)
         {
-            int* m = mmeta + 4*(nmax + w);
+            int* m = mmeta + MM*(nmax + w);
             m[0] = idx_minor_upper[w]; m[1] = minor_scales_with_density_upper[w] ? 1 : 0;
             m[2] = idx_minor_scaling_upper[w]; m[3] = scale_by_complement_upper[w] ? 1 : 0;
+            m[4] = minor_limits_gpt_upper[2*w]; m[5] = minor_limits_gpt_upper[2*w+1]; m[6] = kminor_start_upper[w];
         }
     }
-    const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gpoint_flavor,
-            nminorlower, minor_limits_gpt_lower, kminor_start_lower,
-            nminorupper, minor_limits_gpt_upper, kminor_start_upper);
+    __syncthreads();                  // the chunk lists below are built from the LDS copy of the interval limits
+    const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gflav, ngpt, mmeta, nminorlower, nminorupper);
     __syncthreads();
 
     const int icol = blockIdx.x*blockDim.x + threadIdx.x;
@@ -253,7 +253,7 @@ tau_absorption_kernel(
     // (the scaling gas defaults to index 0 = col_dry where there is none: loaded, not used)
     auto minor_scaling = [&](const int imnr) -> F
     {
-        const int* m = mmeta + 4*(itropo*nmax + imnr);
+        const int* m = mmeta + MM*(itropo*nmax + imnr);
         const int imn = m[0], swd = m[1], ims = m[2], sbc = m[3];
         F scaling = col_gas[idx + size_t(imn)*ncl];
         const F cscal = col_gas[idx + size_t(max(ims, 0))*ncl];
@@ -769,7 +769,7 @@ int tau_absorption_impl(
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = std::max(nminorlower, nminorupper);
-    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax) + size_t(8)*nmax)*sizeof(int);
+    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax) + size_t(2)*MM*nmax)*sizeof(int);
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
