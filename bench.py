@@ -100,6 +100,7 @@ def main():
                          "per-gpoint: per-g-point fluxes stored, then sum_broadband (the reference GPU path's flow)")
     ap.add_argument("--broadband", action="store_true", help="same as --flux-mode broadband")
     ap.add_argument("--per-gpoint", action="store_true", help="same as --flux-mode per-gpoint")
+    ap.add_argument("--bb-min-groups", type=int, default=None, help="rrx_set_broadband_min_groups (A/B of the fused broadband form)")
     ap.add_argument("--lw-variant", type=int, default=0)
     ap.add_argument("--sw-variant", type=int, default=0)
     ap.add_argument("--cpu-cols", type=int, default=6000, help="columns of the CPU baseline sample (0 = skip)")
@@ -126,6 +127,8 @@ def main():
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     be = R.HipKernels(np_dtype, device)
     be.set_variant(lw=args.lw_variant, sw=args.sw_variant)
+    if args.bb_min_groups is not None:
+        be.set_broadband_min_groups(args.bb_min_groups)
     nbnd = args.ngpt // 16
     kd_lw0 = synthetic.make_kdist("lw", ngpt=args.ngpt, nbnd=nbnd)
     kd_sw0 = synthetic.make_kdist("sw", ngpt=args.ngpt, nbnd=nbnd)

@@ -52,7 +52,7 @@ int rrx_subset_nd(void* out, const void* in, int elem_bytes, int ndim, const int
 int rrx_set_lw_variant(int v);
 int rrx_set_sw_variant(int v);
 /* column groups (8 or 16 columns x all levels) below which do_broadband falls back from the fused one-kernel form to
-   per-g-point fluxes in a workspace + sum (default 1024; 1 = always fused) */
+   per-g-point fluxes in a workspace + sum (default 512: measured break-even at C4 shapes is 256-512; 1 = always fused) */
 int rrx_set_broadband_min_groups(int n);
 
 #define RRX_DECLARE(F, SFX) \

@@ -21,7 +21,7 @@ namespace rrx
 {
 // column groups (8*V columns x all levels) needed before the solvers take the fused broadband form: below that the
 // groups alone do not fill the chip and splitting the g-point range would change the summation order
-int g_bb_min_groups = 1024;
+int g_bb_min_groups = 512;       // measured: fused wins from 4096 fp64 columns (512 groups) up, the workspace form below 2048
 }
 
 namespace

@@ -333,7 +333,7 @@ class HipKernels:
         return out
 
     def set_broadband_min_groups(self, n):
-        """column groups needed before do_broadband takes the fused one-kernel form (default 1024; 1 = always)"""
+        """column groups needed before do_broadband takes the fused one-kernel form (default 512; 1 = always)"""
         self.lib.call("rrx_set_broadband_min_groups", int(n))
 
     def set_variant(self, lw=None, sw=None):

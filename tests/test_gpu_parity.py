@@ -90,7 +90,7 @@ def test_broadband_mode_equals_sum_of_gpoints(kind, fused, ncol, nlay, top_at_1,
             r, _ = _solve_both(hip_f64, hip_f64, kind, ncol, nlay, top_at_1, False, do_broadband=bb)
             h.append(r)
     finally:
-        hip_f64.set_broadband_min_groups(1024)
+        hip_f64.set_broadband_min_groups(512)
     for k in ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ()):
         assert cases.rel_err(h[1][k], h[0][k]) <= 1e-12, k
 
@@ -127,7 +127,7 @@ def test_fused_broadband_solvers_sum_gpoints_in_order(dt, top_at_1, hip_f64, hip
             one = [be.to_numpy(x) for x in solve(slice(ig, ig+1), True)]
             seq = one if seq is None else [a_ + b_ for a_, b_ in zip(seq, one)]
     finally:
-        be.set_broadband_min_groups(1024)
+        be.set_broadband_min_groups(512)
     for name, a_, b_, c_ in zip(names, fused, seq, stored):
         assert a_.shape == b_.shape == (nlay+1, ncol) and a_.dtype == b_.dtype
         assert np.array_equal(a_, b_), name
