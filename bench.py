@@ -63,9 +63,12 @@ def pmc_traffic(stage, args):
     return None
 
 
-def cpu_baseline(args, kd_lw0, kd_sw0):
+def cpu_baseline(args, kd_lw0, kd_sw0, be=None):
     """The oracle (scalar C++ port of the reference CPU path, oracle/rrtmgp_oracle.cpp) on a bounded sample of the
-    same workload: `cpu_cols` columns in 12-column blocks like src_test/Radiation_solver.cpp:409, one thread."""
+    same workload: `cpu_cols` columns in 12-column blocks like src_test/Radiation_solver.cpp:409. `value` is ONE thread (the
+    reference CPU executable is single-threaded); `all_cores_value` spreads the same blocks over one process per host core.
+    `parity_max_rel`: the first 12-column block solved by the HIP path as well, max |dflux| / max(|flux|, 1) over the
+    broadband fluxes (must stay below 1e-6)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     from rte_rrtmgp_cpp_amd import synthetic, pipeline
@@ -74,16 +77,42 @@ def cpu_baseline(args, kd_lw0, kd_sw0):
     orc = oracle_py.CpuKernels("oracle", np.float64)
     kd_lw, kd_sw = orc.upload_kdist(kd_lw0), orc.upload_kdist(kd_sw0)
     ncols = args.cpu_cols
+    starts = list(range(0, ncols, 12))
     blocks = [synthetic.make_atmosphere(min(12, ncols - c0), args.nlay, nbnd_lw=kd_lw0.nbnd, nbnd_sw=kd_sw0.nbnd, seed=1234 + c0)
-              for c0 in range(0, ncols, 12)]
+              for c0 in starts]
+    first = None
     t0 = time.perf_counter()
     for sub in blocks:
-        pipeline.solve_lw(orc, kd_lw, sub, do_broadband=True)
-        pipeline.solve_sw(orc, kd_sw, sub, do_broadband=True, fused_gas=False)
+        rl = pipeline.solve_lw(orc, kd_lw, sub, do_broadband=True)
+        rs = pipeline.solve_sw(orc, kd_sw, sub, do_broadband=True, fused_gas=False)
+        if first is None:
+            first = (rl, rs)
     dt = time.perf_counter() - t0
-    return dict(value=ncols/dt, unit="columns/s", cores=1, kind="port",
-                sample=f"{ncols} columns x {args.nlay} layers x {kd_lw0.ngpt}+{kd_sw0.ngpt} g-points, LW+SW clear-sky, "
-                       f"12-column blocks, fp64, broadband mode, {dt:.1f} s")
+    out = dict(value=ncols/dt, unit="columns/s", cores=1, kind="port",
+               sample=f"{ncols} columns x {args.nlay} layers x {kd_lw0.ngpt}+{kd_sw0.ngpt} g-points, LW+SW clear-sky, "
+                      f"12-column blocks, fp64, broadband mode, {dt:.1f} s")
+
+    if be is not None and be.np_dtype == np.float64:
+        sub = pipeline.upload_atmosphere(be, blocks[0])
+        gl = pipeline.solve_lw(be, be.upload_kdist(kd_lw0), sub, do_broadband=True)
+        gs = pipeline.solve_sw(be, be.upload_kdist(kd_sw0), sub, do_broadband=True)
+        worst = 0.0
+        for ref, got in ((first[0], gl), (first[1], gs)):
+            for k in ("flux_up", "flux_dn", "flux_net"):
+                a, b = np.asarray(ref[k], dtype=np.float64), be.to_numpy(got[k]).astype(np.float64)
+                worst = max(worst, float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))))
+        out["parity_max_rel"] = worst
+
+    ncore = min(os.cpu_count() or 1, 16, len(starts))
+    if ncore > 1:
+        import multiprocessing as mp
+        import cpu_worker
+        jobs = [(args.nlay, kd_lw0.ngpt, kd_lw0.nbnd, starts[w::ncore], ncols) for w in range(ncore)]
+        with mp.get_context("spawn").Pool(ncore) as pool:          # spawn: the workers never inherit the GPU context
+            times = pool.map(cpu_worker.solve_blocks, jobs)
+        out["all_cores"] = ncore
+        out["all_cores_value"] = ncols / max(times)
+    return out
 
 
 def main():
@@ -199,7 +228,7 @@ def main():
             "finite": finite,
         }
         if world == 1 and args.cpu_cols > 0:
-            out["cpu_baseline"] = cpu_baseline(args, kd_lw0, kd_sw0)
+            out["cpu_baseline"] = cpu_baseline(args, kd_lw0, kd_sw0, be)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
