@@ -65,8 +65,9 @@ def read_output(d):
 
 
 @pytest.mark.parametrize("clouds", [False, True])
-def test_driver_matches_pipeline_and_oracle(case, clouds, hip_f64, oracle_f64):
-    flags = ["--cloud-optics"] if clouds else []
+@pytest.mark.parametrize("broadband", [True, False], ids=["broadband-solvers", "per-gpoint"])
+def test_driver_matches_pipeline_and_oracle(case, clouds, broadband, hip_f64, oracle_f64):
+    flags = (["--cloud-optics"] if clouds else []) + ([] if broadband else ["--no-broadband-solvers"])
     assert run_driver(case["dir"], *flags, "--output-optical") == 0
     _, out = read_output(case["dir"])
     hip = reference_fluxes(hip_f64, case, clouds)
@@ -94,6 +95,15 @@ def test_driver_column_blocks_bands_and_broadband_mode(case, hip_f64):
     # broadband solvers (the CPU path's convention): same fluxes without per-g-point arrays
     assert run_driver(case["dir"], "--cloud-optics", "--broadband-solvers", "--no-delta-cloud") == 0
     assert run_driver(case["dir"], "--cloud-optics", "--broadband-solvers") == 0
+    _, out = read_output(case["dir"])
+    for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net"):
+        assert cases.rel_err(out[k], hip[k]) <= 1e-11, k
+    # ... and with the fused one-kernel form of the broadband solvers forced (it needs >= 512 column groups by default)
+    hip_f64.set_broadband_min_groups(1)
+    try:
+        assert run_driver(case["dir"], "--cloud-optics", env={"RRX_COL_BLOCK": "16"}) == 0
+    finally:
+        hip_f64.set_broadband_min_groups(512)
     _, out = read_output(case["dir"])
     for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net"):
         assert cases.rel_err(out[k], hip[k]) <= 1e-11, k
