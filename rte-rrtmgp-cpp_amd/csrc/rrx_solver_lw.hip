@@ -35,7 +35,7 @@ constexpr int LL = 8;    // level lanes
 // registers (same summation order as sum_broadband over stored per-g-point fluxes, so the same bits); flux_up/flux_dn
 // are then (ncol, nlev) arrays. Saves the per-g-point flux stores and the reduction pass that reads them back.
 template<typename F, int V, int K, int W, bool JAC, bool ACC, bool BB = false>
-__global__ void __launch_bounds__(256, (W == 2) ? 2 : 1)
+__global__ void __launch_bounds__(256, (W >= 2) ? 2 : 1)
 lw_noscat_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
         const F* __restrict__ secants, const F* __restrict__ weights,
@@ -48,9 +48,9 @@ lw_noscat_scan_kernel(
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
-    const int h = (W == 2) ? (wave & 1) : 0;         // which half of the column this wave holds (0 = TOA side)
+    const int h = wave % W;                          // which part of the column this wave holds (0 = TOA side)
     const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
-    __shared__ F xch[(W == 2) ? 4*V : 1][4][CL];     // wave totals of the two scans
+    __shared__ F xch[(W >= 2) ? 4*V : 1][4][CL];     // wave totals of the two scans
     // The two waves that share each 128-B line (8 columns x 8 B = 64 B per wave when V = 1) must issue their load
     // bursts together, or the second half of every line is fetched from HBM again once L2 has turned over
     // (measured: +26 % FETCH_SIZE without the barrier). No thread leaves before the barrier.
@@ -106,7 +106,7 @@ lw_noscat_scan_kernel(
     Vec<F,V> lv_next;
     #pragma unroll
     for (int v=0; v<V; ++v) lv_next.v[v] = shfl(lv[0].v[v], lane + CL);
-    if constexpr (W == 2)
+    if constexpr (W >= 2)
     {
         if (ll == LL-1)
         {
@@ -181,14 +181,22 @@ lw_noscat_scan_kernel(
         }
         F xa = F(1.), xb = F(0.);                               // composite of the levels above this wave's
         F fa = shfl(a, (LL-1)*CL + cl), fb = shfl(b, (LL-1)*CL + cl);   // composite of the whole column
-        if constexpr (W == 2)
+        if constexpr (W >= 2)
         {
+            // every wave publishes the composite of its part; (xa, xb) = the parts above this wave's, TOA side first;
+            // (fa, fb) = all parts, composed in the same order by every wave (bit-identical dn_sfc in all of them)
             if (ll == LL-1) { xch[4*v+0][wave][cl] = a; xch[4*v+1][wave][cl] = b; }
             __syncthreads();
-            const F oa = xch[4*v+0][wave^1][cl], ob = xch[4*v+1][wave^1][cl];
-            if (h == 1) { xa = oa; xb = ob; b = a*xb + b; a = a*xa; }
-            fb = (h == 0) ? oa*fb + ob : fa*ob + fb;
-            fa = fa*oa;
+            const int w0 = wave - h;                     // first wave of this column group
+            fa = F(1.); fb = F(0.);
+            #pragma unroll
+            for (int w=0; w<W; ++w)
+            {
+                const F oa = xch[4*v+0][w0+w][cl], ob = xch[4*v+1][w0+w][cl];
+                if (w == h) { xa = fa; xb = fb; }
+                fb = oa*fb + ob; fa = oa*fa;
+            }
+            if (h > 0) { b = a*xb + b; a = a*xa; }
         }
         F ae = shfl(a, lane - CL), be = shfl(b, lane - CL);     // exclusive
         if (ll == 0) { ae = xa; be = xb; }
@@ -209,11 +217,21 @@ lw_noscat_scan_kernel(
             if (ll + d < LL) { b = a*b2 + b; a = a*a2; }
         }
         xa = F(1.); xb = F(0.);                                 // composite of the levels below this wave's
-        if constexpr (W == 2)
+        if constexpr (W >= 2)
         {
             if (ll == 0) { xch[4*v+2][wave][cl] = a; xch[4*v+3][wave][cl] = b; }
             __syncthreads();
-            if (h == 0) { xa = xch[4*v+2][wave^1][cl]; xb = xch[4*v+3][wave^1][cl]; b = a*xb + b; a = a*xa; }
+            const int w0 = wave - h;
+            #pragma unroll
+            for (int w=W-1; w>=1; --w)                   // the parts below this wave's, surface side first
+            {
+                if (w > h)
+                {
+                    const F oa = xch[4*v+2][w0+w][cl], ob = xch[4*v+3][w0+w][cl];
+                    xb = oa*xb + ob; xa = oa*xa;
+                }
+            }
+            if (h < W-1) { b = a*xb + b; a = a*xa; }
         }
         ae = shfl(a, lane + CL); be = shfl(b, lane + CL);
         if (ll == LL-1) { ae = xa; be = xb; }
@@ -442,14 +460,16 @@ bool launch_scan(
     const dim3 grid(ceil_div(ncol, (4/W)*CL*V), ngpt);
     const int need = ceil_div(nlay+1, LL*W);
 #define RRX_LW_K(KK) if (need <= KK) { launch_scan_k<F,V,KK,W>(st, grid, jac, acc, RRX_LW_ARGS); return true; }
-    if constexpr (W == 1) { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) RRX_LW_K(24) RRX_LW_K(33) }
-    else                  { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) RRX_LW_K(17) }
+    if constexpr (W == 1)      { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) RRX_LW_K(24) RRX_LW_K(33) }
+    else if constexpr (W == 2) { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) RRX_LW_K(17) }
+    else                       { RRX_LW_K(2) RRX_LW_K(3) RRX_LW_K(5) }
 #undef RRX_LW_K
     return false;
 }
 
 // 0 = default, 1 = serial fallback, 2 = one wave/V=1, 3 = one wave/wide rows, 4 = two waves/64-B rows,
-// 5 = two waves/128-B rows, 6 = one wave/64-B rows, 7 = default kernels but never the fused broadband form
+// 5 = two waves/128-B rows, 6 = one wave/64-B rows, 7 = default kernels but never the fused broadband form,
+// 10 = four waves/128-B rows (per-g-point form), 8 / 9 = fused broadband form with two / four waves per column group (default: two in fp64, four in fp32)
 // fused broadband form: one workgroup walks all g-points of its columns (grid.y = 1)
 template<typename F, int V, int W>
 bool launch_scan_bb(
@@ -462,8 +482,9 @@ bool launch_scan_bb(
     const int imu = 0;
     const F* sfc_src_jac = nullptr; F* flux_up_jac = nullptr;
 #define RRX_LW_K(KK) if (need <= KK) { lw_noscat_scan_kernel<F,V,KK,W,false,false,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS); return true; }
-    if constexpr (W == 1) { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) }
-    else                  { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) }
+    if constexpr (W == 1)      { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) }
+    else if constexpr (W == 2) { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) }
+    else                       { RRX_LW_K(2) RRX_LW_K(3) RRX_LW_K(5) }     // taller columns spill at 128-B rows: W = 2 form
 #undef RRX_LW_K
     return false;
 }
@@ -497,6 +518,14 @@ int lw_solver_noscat_impl(
         && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
+        // four waves per column group (K = 5 at 140 layers) leave room for the g-point sums AND 128-B row segments.
+        // Measured at C4: fp32 2.15 ms against 2.28 ms with two waves / 64-B rows; fp64 3.94 against 3.15 ms (256 VGPRs,
+        // 12 % idle level-lanes), so fp64 keeps two waves unless variant 9 asks for four.
+        const bool four = (g_lw_variant == 9) || (g_lw_variant != 8 && sizeof(F) == 4);
+        if (four && ncol % (2*VBB) == 0 &&
+            launch_scan_bb<F,2*VBB,4>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
+            return 0;
         if (launch_scan_bb<F,VBB,2>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                     sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return 0;
@@ -526,7 +555,8 @@ int lw_solver_noscat_impl(
         if (g_lw_variant != 1)
         {
             const int var = (g_lw_variant == 0) ? RRX_LW_DEFAULT_VARIANT : g_lw_variant;
-            if (var == 3 && ncol % VMAX == 0)      done = launch_scan<F,VMAX,1>(st, jac, acc, RRX_LW_ARGS_CALL);
+            if (var == 10 && ncol % VMAX == 0)     done = launch_scan<F,VMAX,4>(st, jac, acc, RRX_LW_ARGS_CALL);
+            else if (var == 3 && ncol % VMAX == 0) done = launch_scan<F,VMAX,1>(st, jac, acc, RRX_LW_ARGS_CALL);
             else if (var == 6 && ncol % VDEF == 0) done = launch_scan<F,VDEF,1>(st, jac, acc, RRX_LW_ARGS_CALL);
             else if (var == 2)                     done = launch_scan<F,1,1>(st, jac, acc, RRX_LW_ARGS_CALL);
             else if (var != 4 && ncol % VMAX == 0) done = launch_scan<F,VMAX,2>(st, jac, acc, RRX_LW_ARGS_CALL);
