@@ -574,6 +574,9 @@ struct CellInterp
     }
 };
 
+#ifndef RRX_PLANCK_MINWAVES
+#define RRX_PLANCK_MINWAVES 1
+#endif
 #ifndef RRX_PLANCK_PL
 #define RRX_PLANCK_PL 4
 #endif
@@ -584,7 +587,7 @@ constexpr int PL = RRX_PLANCK_PL; // layers per Planck workgroup (64 columns x P
 // cell). Here a workgroup of 64 columns x 8 layers exchanges the fractions through LDS in chunks of 16 g-points,
 // so only the first layer of each workgroup recomputes its neighbour (9 gathers per cell on average).
 template<typename F>
-__global__ void __launch_bounds__(64*PL)
+__global__ void __launch_bounds__(64*PL, RRX_PLANCK_MINWAVES)
 planck_source_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp, const int nPlanckTemp,
         const F* __restrict__ tlay, const F* __restrict__ tlev, const F* __restrict__ tsfc, const int sfc_lay,
@@ -593,11 +596,15 @@ planck_source_kernel(
         const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
         const F temp_ref_min, const F totplnk_delta, const F* __restrict__ totplnk,
         const int* __restrict__ gpoint_flavor,
-        F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac)
+        F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac, const int share_on)
 {
     extern __shared__ double lds_raw[];
     F* pf = reinterpret_cast<F*>(lds_raw);            // [GCH][PL+1][64]; slot 0 = layer below the workgroup
     int* gflav = reinterpret_cast<int*>(pf + GCH*(PL+1)*64);   // [2][ngpt] flavor (0-based) per regime and g-point
+    // per-wavefront staging area of the shared-cell path below: [2 sets][4 corners][16 g-points] temperature pairs
+    typedef F Vec2 __attribute__((ext_vector_type(2)));
+    typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
+    Vec2* stg = reinterpret_cast<Vec2*>(gflav + ((2*ngpt + 3) & ~3)) + size_t(threadIdx.y)*2*4*GCH;
     for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*PL)
         gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
     __syncthreads();
@@ -639,10 +646,53 @@ planck_source_kernel(
     constexpr int PG = 4;
     auto fractions = [&](CellInterp<F>& ci, int& cur, const size_t cell_idx, const int itr, const int ig0, const int gend, const int slot)
     {
+        // one regime per wavefront <=> the flavor of a g-point is the same in all lanes and this loop runs convergent
+        const bool one_regime = share_on && __all(itr == __builtin_amdgcn_readfirstlane(itr));
         for (int ig=ig0; ig<gend; )
         {
             const int fl = gflav[itr*ngpt + ig];
             if (fl != cur) { cur = fl; ci.load(cell_idx + size_t(fl)*ncl, fmajor, jeta); }
+
+            // Shared-cell path: when the 64 columns of the wavefront sit in the same LUT cell for this flavor (the rule at
+            // one level of an LES domain), the 8 corners x up to 16 g-points of the band are fetched ONCE per wavefront --
+            // lane = (corner pair, g-point), one or two 2-word loads -- and every lane combines them with its own weights
+            // through broadcast LDS reads: 1-2 wave-loads per band instead of 4 per g-point. Same words, same sums.
+            if (one_regime)
+            {
+                const int jt0 = __builtin_amdgcn_readfirstlane(ci.jt), jp0 = __builtin_amdgcn_readfirstlane(ci.jp);
+                const int e0 = __builtin_amdgcn_readfirstlane(ci.je[0]), e1 = __builtin_amdgcn_readfirstlane(ci.je[1]);
+                if (__all(ci.jt == jt0 && ci.jp == jp0 && ci.je[0] == e0 && ci.je[1] == e1))
+                {
+                    int gr = ig + 1;
+                    while (gr < gend && gflav[itr*ngpt + gr] == fl) ++gr;
+                    const int ng = gr - ig;                                   // <= GCH
+                    const int c = tx >> 4, gi = tx & 15;
+                    const size_t oc = size_t(jt0-1) + size_t(e0-1 + (c & 1))*s_eta + size_t(jp0-1 + (c >> 1))*s_prs;
+                    Vec2 qa = Vec2{F(0.), F(0.)}, qb = qa;
+                    if (gi < ng)
+                    {
+                        const F* src = pfracin + size_t(ig + gi)*s_gpt + oc;
+                        qa = *reinterpret_cast<const Vec2u*>(src);
+                        if (e0 != e1) qb = *reinterpret_cast<const Vec2u*>(src + (e1 - e0)*ptrdiff_t(s_eta));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    stg[c*GCH + gi] = qa;
+                    stg[(4 + c)*GCH + gi] = qb;
+                    __builtin_amdgcn_wave_barrier();
+                    #pragma unroll 4
+                    for (int g=0; g<ng; ++g)
+                    {
+                        const Vec2 q0 = stg[g], q1 = stg[GCH + g], q2 = stg[2*GCH + g], q3 = stg[3*GCH + g];
+                        F v4 = q0.y, v5 = q1.y, v6 = q2.y, v7 = q3.y;
+                        if (e0 != e1) { v4 = stg[4*GCH + g].y; v5 = stg[5*GCH + g].y; v6 = stg[6*GCH + g].y; v7 = stg[7*GCH + g].y; }
+                        pf[((ig + g - ig0)*(PL+1) + slot)*64 + tx] =
+                            (ci.fm[0]*q0.x + ci.fm[1]*q1.x + ci.fm[2]*q2.x + ci.fm[3]*q3.x)
+                          + (ci.fm[4]*v4 + ci.fm[5]*v5 + ci.fm[6]*v6 + ci.fm[7]*v7);
+                    }
+                    ig = gr;
+                    continue;
+                }
+            }
             int ge = min(ig + PG, gend);
             #pragma unroll
             for (int u=PG-1; u>=1; --u)
@@ -744,6 +794,9 @@ __global__ void reorder12x21_kernel(const int ni, const int nj, const F* __restr
         out[o] = in[ij + size_t(ii)*nj];
     }
 }
+
+// shared-cell path of the gather kernels (RRX_GO_SHARE=0 turns it off for A/B runs)
+int g_go_share = getenv("RRX_GO_SHARE") ? atoi(getenv("RRX_GO_SHARE")) : 1;
 
 inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*8)); }
 
@@ -906,9 +959,9 @@ int rrx_compute_planck_source##SFX( \
     RRX_TRY \
     (void)nbnd; (void)nflav; (void)band_lims_gpt; \
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
-    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F) + size_t(2)*ngpt*sizeof(int), static_cast<hipStream_t>(stream)>>>( \
+    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F) + size_t((2*ngpt + 3) & ~3)*sizeof(int) + size_t(PL)*2*4*GCH*2*sizeof(F), static_cast<hipStream_t>(stream)>>>( \
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
-            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac); \
+            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac, g_go_share); \
     RRX_CATCH("rrx_compute_planck_source") \
 } \
 int rrx_reorder123x321##SFX(int ni, int nj, int nk, const F* arr_in, F* arr_out, void* stream) \
