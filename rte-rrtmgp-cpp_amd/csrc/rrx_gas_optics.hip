@@ -107,6 +107,8 @@ struct MinorIndex
 };
 
 constexpr int MM = 8;        // ints per contributor in the LDS constant table
+__device__ __forceinline__ int rfl(const int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 __device__ inline MinorIndex build_minor_index(
         int* lds, const int nchunk, const int nmax, const int* gflav, const int ngpt,
         const int* mmeta, const int nminorlower, const int nminorupper)
@@ -249,12 +251,20 @@ tau_absorption_kernel(
     F ray_fac = F(0.);
     if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
 
+    // One pass per regime (lower / upper atmosphere): inside a pass every active lane is in regime `itr`, so everything
+    // that depends on the regime and the g-point only -- flavor, minor-contributor lists, table bases, loop bounds -- is
+    // wave-uniform. readfirstlane (first ACTIVE lane) puts those values into SGPRs: conditions and table addresses
+    // become scalar, inactive contributors cost a scalar branch. A wavefront whose columns are all in one regime (the
+    // rule: pressure is nearly constant along a level) skips the other pass; one that straddles the tropopause runs both.
+    for (int itr=0; itr<2; ++itr)
+    {
+    if (itropo != itr) continue;
     // /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:505-529; both column amounts are requested at once
     // (the scaling gas defaults to index 0 = col_dry where there is none: loaded, not used)
     auto minor_scaling = [&](const int imnr) -> F
     {
-        const int* m = mmeta + MM*(itropo*nmax + imnr);
-        const int imn = m[0], swd = m[1], ims = m[2], sbc = m[3];
+        const int* m = mmeta + MM*(itr*nmax + imnr);
+        const int imn = rfl(m[0]), swd = rfl(m[1]), ims = rfl(m[2]), sbc = rfl(m[3]);
         F scaling = col_gas[idx + size_t(imn)*ncl];
         const F cscal = col_gas[idx + size_t(max(ims, 0))*ncl];
         if (swd)
@@ -340,7 +350,7 @@ tau_absorption_kernel(
             #pragma unroll
             for (int u=0; u<G; ++u)
             {
-                const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(igs[u])*tn;
+                const F* kr = krayl + size_t(itr)*tn*ngpt + size_t(igs[u])*tn;
                 const Pair<F> r0 = ld2(kr, q0a), r1 = ld2(kr, q0b);
                 rv[u][0] = r0.x; rv[u][1] = r1.x; rv[u][2] = r0.y; rv[u][3] = r1.y;
             }
@@ -349,7 +359,7 @@ tau_absorption_kernel(
                 #pragma unroll
                 for (int u=0; u<G; ++u)
                 {
-                    const F* kr = krayl + size_t(itropo)*tn*ngpt + size_t(igs[u])*tn;
+                    const F* kr = krayl + size_t(itr)*tn*ngpt + size_t(igs[u])*tn;
                     rv[u][2] = ld(kr, q1a); rv[u][3] = ld(kr, q1b);
                 }
             }
@@ -361,7 +371,7 @@ tau_absorption_kernel(
             for (int u=0; u<G; ++u) told[u] = tau[idx + size_t(igs[u])*ncl];
         }
 
-        const F* kmin = itropo == 0 ? kminor_lower : kminor_upper;
+        const F* kmin = itr == 0 ? kminor_lower : kminor_upper;
         auto minor_active = [&](const int i) -> bool { return i < n && ig0 < sl.hi[i] && ig0 + G > sl.lo[i]; };
         auto minor_load = [&](const int i, F (&mv)[G][4])
         {
@@ -416,7 +426,8 @@ tau_absorption_kernel(
         }
         for (int i=SL; i<n; ++i)                          // more than SL contributors in one chunk: rare
         {
-            const int* it = mi.item(itropo, c, i);
+            const int* itp = mi.item(itr, c, i);
+            const int it[5] = {rfl(itp[0]), rfl(itp[1]), rfl(itp[2]), rfl(itp[3]), rfl(itp[4])};
             #pragma unroll
             for (int u=0; u<G; ++u)
                 if (igs[u] >= it[1] && igs[u] < it[2])
@@ -457,7 +468,7 @@ tau_absorption_kernel(
     for (int c=0; c<nchunk; ++c)
     {
         const int c0 = c*GCH;
-        const int n = mi.count(itropo, c);
+        const int n = rfl(mi.count(itr, c));
         const int gend = min(c0 + GCH, ngpt);
 
         // this chunk's minor contributors: parameters and per-cell scaling in registers
@@ -465,25 +476,26 @@ tau_absorption_kernel(
         #pragma unroll
         for (int i=0; i<SL; ++i)
         {
-            const int* it = mi.item(itropo, c, min(i, max(n-1, 0)));
-            sl.lo[i] = it[1]; sl.hi[i] = it[2]; sl.koff[i] = it[3]; sl.mf[i] = it[4];
+            const int* it = mi.item(itr, c, min(i, max(n-1, 0)));
+            sl.lo[i] = rfl(it[1]); sl.hi[i] = rfl(it[2]); sl.koff[i] = rfl(it[3]); sl.mf[i] = rfl(it[4]);
             sc[i] = F(0.);
-            if (i < n) sc[i] = minor_scaling(it[0]);
+            if (i < n) sc[i] = minor_scaling(rfl(it[0]));
         }
 
         for (int ig0=c0; ig0<gend; )
         {
             // a group never straddles a flavor change (of either regime, so that group bounds stay wave-uniform)
-            const int iflav = gflav[itropo*ngpt + ig0];
+            const int iflav = rfl(gflav[itr*ngpt + ig0]);
             if (iflav != cur_flav) load_flavor(iflav);
             int ge = min(ig0 + G, gend);
             #pragma unroll
             for (int u=G-1; u>=1; --u)
-                if (ig0 + u < gend && gchg[ig0 + u]) ge = ig0 + u;
+                if (ig0 + u < gend && rfl(gchg[ig0 + u])) ge = ig0 + u;
             gpoint_group(ig0, ge, c, n, sl, sc);
             ig0 = ge;
         }
     }
+    }   // regime passes
 }
 
 

@@ -136,6 +136,35 @@ def test_fused_broadband_solvers_sum_gpoints_in_order(dt, top_at_1, hip_f64, hip
         assert cases.rel_err(a_, c_) <= (1e-13 if dt == "f64" else 1e-3), name
 
 
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_columns_in_different_regimes_within_one_wavefront(kind, hip_f64, oracle_f64):
+    """Columns whose pressure at the same layer differs by up to +-35 %: wavefronts (64 columns of one layer) straddle the
+    tropopause and the LUT cell boundaries, i.e. both regime passes of the absorption kernel run, the shared-cell path of
+    the Planck kernel is refused lane by lane, and minor-contributor lists differ between lanes."""
+    ncol, nlay, ngpt, nbnd = 130, 60, 64, 4
+    kd0 = synthetic.make_kdist(kind, ngpt=ngpt, nbnd=nbnd, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=7)
+    rng = np.random.default_rng(8)
+    scale = rng.uniform(0.65, 1.35, ncol)
+    atm0.p_lay = np.ascontiguousarray(atm0.p_lay * scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * scale[None, :])
+    atm0.t_lay = np.ascontiguousarray(atm0.t_lay + rng.uniform(-12, 12, ncol)[None, :])
+    res = []
+    for be in (hip_f64, oracle_f64):
+        kd = be.upload_kdist(kd0)
+        atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
+        fn = pipeline.solve_lw if kind == "lw" else pipeline.solve_sw
+        r = fn(be, kd, atm, keep=True)
+        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
+    h, o = res
+    okd = oracle_f64.upload_kdist(kd0)
+    _, _, it = pipeline.gas_state(oracle_f64, okd, pipeline.upload_atmosphere(oracle_f64, atm0))
+    tr = np.asarray(it["tropo"]).reshape(nlay, ncol)
+    assert ((tr[:, :64].min(axis=1) != tr[:, :64].max(axis=1))).sum() > 0, "the test atmosphere must put a wavefront into both regimes"
+    keys = ("tau", "flux_up", "flux_dn", "flux_net") + (("lay_src", "lev_src") if kind == "lw" else ("ssa", "flux_dn_dir"))
+    for k in keys:
+        assert cases.rel_err(h[k], o[k]) <= (1e-7 if kind == "sw" and k.startswith("flux") else 1e-9), k
+
+
 def test_lw_multi_angle_and_incident_flux(hip_f64, oracle_f64):
     rng = np.random.default_rng(5)
     ngpt, nlay, ncol = 16, 33, 50
