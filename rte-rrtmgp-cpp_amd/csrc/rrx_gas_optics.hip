@@ -376,18 +376,53 @@ tau_absorption_kernel(
         auto minor_active = [&](const int i) -> bool { return i < n && ig0 < sl.hi[i] && ig0 + G > sl.lo[i]; };
         auto minor_load = [&](const int i, F (&mv)[G][4])
         {
-            #pragma unroll
-            for (int u=0; u<G; ++u)
+            if constexpr (sizeof(F) == 4)
             {
-                const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
-                const F* km = kmin + size_t(kg + sl.koff[i])*tn;
-                if (sl.mf[i] == cur_flav)
+                // fp32: one g-point at a time (the batched form below costs this precision its third wave per SIMD:
+                // 163 -> 191 VGPRs, SW 4.4 -> 5.1 ms)
+                #pragma unroll
+                for (int u=0; u<G; ++u)
                 {
-                    const Pair<F> m0 = ld2(km, q0a), m1 = ld2(km, q0b);
-                    mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
-                    if (!same_eta) { mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                    const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);      // clamped: always a valid table row
+                    const F* km = kmin + size_t(kg + sl.koff[i])*tn;
+                    if (sl.mf[i] == cur_flav)
+                    {
+                        const Pair<F> m0 = ld2(km, q0a), m1 = ld2(km, q0b);
+                        mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
+                        if (!same_eta) { mv[u][2] = ld(km, q1a); mv[u][3] = ld(km, q1b); }
+                    }
+                    else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
                 }
-                else { mv[u][0] = minor_other_flavor(sl.mf[i], km); mv[u][1] = mv[u][2] = mv[u][3] = F(0.); }
+            }
+            else if (sl.mf[i] == cur_flav)                                 // wave-uniform
+            {
+                // fp64: straight-line per contributor -- the 2-word loads of all G g-points first, the separate jt-node
+                // loads of lanes whose two temperatures sit in different eta intervals in ONE divergent block afterwards
+                // (a branch inside the g-point loop splits the batch into G dependent pieces): LW 4.55 -> 4.35 ms
+                const F* km[G];
+                #pragma unroll
+                for (int u=0; u<G; ++u)
+                {
+                    const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);
+                    km[u] = kmin + size_t(kg + sl.koff[i])*tn;
+                    const Pair<F> m0 = ld2(km[u], q0a), m1 = ld2(km[u], q0b);
+                    mv[u][0] = m0.x; mv[u][1] = m1.x; mv[u][2] = m0.y; mv[u][3] = m1.y;
+                }
+                if (!same_eta)
+                {
+                    #pragma unroll
+                    for (int u=0; u<G; ++u) { mv[u][2] = ld(km[u], q1a); mv[u][3] = ld(km[u], q1b); }
+                }
+            }
+            else
+            {
+                #pragma unroll
+                for (int u=0; u<G; ++u)
+                {
+                    const int kg = min(max(igs[u], sl.lo[i]), sl.hi[i]-1);
+                    mv[u][0] = minor_other_flavor(sl.mf[i], kmin + size_t(kg + sl.koff[i])*tn);
+                    mv[u][1] = mv[u][2] = mv[u][3] = F(0.);
+                }
             }
         };
 
