@@ -441,14 +441,15 @@ tau_absorption_kernel(
 
         auto minor_accum = [&](const int i, const F (&mv)[G][4])
         {
+            // branch-free over the g-points of the group (rows outside the contributor's interval were loaded from its
+            // nearest valid row and are discarded by the select): no control flow splits the group's instruction stream
+            const bool own = (sl.mf[i] == cur_flav);
             #pragma unroll
             for (int u=0; u<G; ++u)
             {
-                if (igs[u] >= sl.lo[i] && igs[u] < sl.hi[i])
-                {
-                    const F kk = (sl.mf[i] == cur_flav) ? fn0*mv[u][0] + fn1*mv[u][1] + fn2*mv[u][2] + fn3*mv[u][3] : mv[u][0];
-                    t[u] += kk * sc[i];
-                }
+                const F kk = own ? fn0*mv[u][0] + fn1*mv[u][1] + fn2*mv[u][2] + fn3*mv[u][3] : mv[u][0];
+                const F tn_ = t[u] + kk * sc[i];
+                t[u] = (igs[u] >= sl.lo[i] && igs[u] < sl.hi[i]) ? tn_ : t[u];
             }
         };
         #pragma unroll
