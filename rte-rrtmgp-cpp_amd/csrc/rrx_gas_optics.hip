@@ -675,12 +675,17 @@ planck_source_kernel(
     CellInterp<F> own, prev;
     own.jt = jtemp[idx]; own.jp = jpress[idx] + itropo;
     const bool has_prev = ilay > 0;
-    const bool halo = ly == 0 && has_prev;             // this thread also computes the fraction of layer ilay-1
+    // The layer below the workgroup's first one (its fractions enter lev_src of that first layer) is shared out: every
+    // wavefront computes GCH/PL of its g-points per chunk, instead of wavefront 0 doing a second full layer while the
+    // others wait at the barrier (ablation: the fraction phase was 1.8 of 3.55 ms and did not overlap with the rest).
+    const int lay0 = blockIdx.y*PL;
+    const bool halo = lay0 > 0;                        // workgroup-uniform
+    const size_t idx_h = size_t(icol) + size_t(max(lay0-1, 0))*ncol;
     int itropo_m1 = 0;
     if (halo)
     {
-        itropo_m1 = tropo[idx - ncol] ? 0 : 1;
-        prev.jt = jtemp[idx - ncol]; prev.jp = jpress[idx - ncol] + itropo_m1;
+        itropo_m1 = tropo[idx_h] ? 0 : 1;
+        prev.jt = jtemp[idx_h]; prev.jp = jpress[idx_h] + itropo_m1;
     }
     const F t_lay = tlay[idx], t_lev = tlev[idx];
     const bool is_last = ilay == nlay-1;
@@ -693,11 +698,12 @@ planck_source_kernel(
 
     // Planck fractions of up to PG g-points of one cell: all 8*PG gathers are issued before the first use
     constexpr int PG = 4;
-    auto fractions = [&](CellInterp<F>& ci, int& cur, const size_t cell_idx, const int itr, const int ig0, const int gend, const int slot)
+    auto fractions = [&](CellInterp<F>& ci, int& cur, const size_t cell_idx, const int itr, const int ig_first, const int gend, const int slot,
+                         const int ig0)
     {
         // one regime per wavefront <=> the flavor of a g-point is the same in all lanes and this loop runs convergent
         const bool one_regime = share_on && __all(itr == __builtin_amdgcn_readfirstlane(itr));
-        for (int ig=ig0; ig<gend; )
+        for (int ig=ig_first; ig<gend; )
         {
             const int fl = gflav[itr*ngpt + ig];
             if (fl != cur) { cur = fl; ci.load(cell_idx + size_t(fl)*ncl, fmajor, jeta); }
@@ -781,8 +787,13 @@ planck_source_kernel(
     for (int c0=0; c0<ngpt; c0+=GCH)
     {
         const int gend = min(c0 + GCH, ngpt);
-        fractions(own, cur_flav, idx, itropo, c0, gend, ly+1);
-        if (halo) fractions(prev, cur_flav_m1, idx - ncol, itropo_m1, c0, gend, 0);
+        fractions(own, cur_flav, idx, itropo, c0, gend, ly+1, c0);
+        if (halo)
+        {
+            const int q = (gend - c0 + PL - 1) / PL;
+            const int hb = c0 + ly*q, he = min(hb + q, gend);
+            if (hb < he) fractions(prev, cur_flav_m1, idx_h, itropo_m1, hb, he, 0, c0);
+        }
         __syncthreads();
 
         for (int ig=c0; ig<gend; ++ig)
