@@ -34,7 +34,10 @@ constexpr int LL = 8;    // level lanes
 // BB (broadband): the workgroup walks over ALL g-points of its columns and keeps the g-point sum of both fluxes in
 // registers (same summation order as sum_broadband over stored per-g-point fluxes, so the same bits); flux_up/flux_dn
 // are then (ncol, nlev) arrays. Saves the per-g-point flux stores and the reduction pass that reads them back.
-template<typename F, int V, int K, int W, bool JAC, bool ACC, bool BB = false>
+// CLT = column lanes per wavefront (level lanes = 64 / CLT): 8 x 8 is the default geometry; 16 x 4 with W = 4 keeps K = 9
+// layers per lane at 140 layers (the register budget of the two-wave form) and doubles the row segment of a wavefront
+// (128 B in fp64 with V = 1).
+template<typename F, int V, int K, int W, bool JAC, bool ACC, bool BB = false, int CLT = 8>
 __global__ void __launch_bounds__(256, (W >= 2) ? 2 : 1)
 lw_noscat_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1, const int imu,
@@ -46,8 +49,9 @@ lw_noscat_scan_kernel(
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    constexpr int CL = CLT, LL = 64 / CLT;           // shadow the default geometry
     const int cl = lane & (CL-1);
-    const int ll = lane >> 3;
+    const int ll = lane / CL;
     const int h = wave % W;                          // which part of the column this wave holds (0 = TOA side)
     const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
     __shared__ F xch[(W >= 2) ? 4*V : 1][4][CL];     // wave totals of the two scans
@@ -469,7 +473,8 @@ bool launch_scan(
 
 // 0 = default, 1 = serial fallback, 2 = one wave/V=1, 3 = one wave/wide rows, 4 = two waves/64-B rows,
 // 5 = two waves/128-B rows, 6 = one wave/64-B rows, 7 = default kernels but never the fused broadband form,
-// 10 = four waves/128-B rows (per-g-point form), 8 / 9 = fused broadband form with two / four waves per column group (default: two in fp64, four in fp32)
+// 10 = four waves/128-B rows (per-g-point form), 8 / 9 / 12 = fused broadband form with two / four waves of 8 x 8 lanes / four waves of 16 x 4 lanes
+// (default: 12 in fp64, 9 in fp32)
 // fused broadband form: one workgroup walks all g-points of its columns (grid.y = 1)
 template<typename F, int V, int W>
 bool launch_scan_bb(
@@ -485,6 +490,23 @@ bool launch_scan_bb(
     if constexpr (W == 1)      { RRX_LW_K(4) RRX_LW_K(8) RRX_LW_K(12) RRX_LW_K(18) }
     else if constexpr (W == 2) { RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6)  RRX_LW_K(9)  RRX_LW_K(12) }
     else                       { RRX_LW_K(2) RRX_LW_K(3) RRX_LW_K(5) }     // taller columns spill at 128-B rows: W = 2 form
+#undef RRX_LW_K
+    return false;
+}
+
+// fused broadband form in the 16 column-lane x 4 level-lane geometry, four waves per column group
+template<typename F, int V>
+bool launch_scan_bb16(
+        hipStream_t st, const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
+{
+    const dim3 grid(ceil_div(ncol, 16*V), 1);
+    const int need = ceil_div(nlay+1, 4*4);
+    const int imu = 0;
+    const F* sfc_src_jac = nullptr; F* flux_up_jac = nullptr;
+#define RRX_LW_K(KK) if (need <= KK) { lw_noscat_scan_kernel<F,V,KK,4,false,false,true,16><<<grid, 256, 0, st>>>(RRX_LW_KARGS); return true; }
+    RRX_LW_K(2) RRX_LW_K(4) RRX_LW_K(6) RRX_LW_K(9) RRX_LW_K(12)
 #undef RRX_LW_K
     return false;
 }
@@ -521,6 +543,12 @@ int lw_solver_noscat_impl(
         // four waves per column group (K = 5 at 140 layers) leave room for the g-point sums AND 128-B row segments.
         // Measured at C4: fp32 2.15 ms against 2.28 ms with two waves / 64-B rows; fp64 3.94 against 3.15 ms (256 VGPRs,
         // 12 % idle level-lanes), so fp64 keeps two waves unless variant 9 asks for four.
+        // fp64 default: 16 x 4 lane geometry over four waves (128-B rows at K = 9: 3.00 -> 2.84 ms at C4; fp32 prefers the
+        // 8 x 8 geometry with four waves and V = 4, 2.16 against 2.28 ms)
+        if ((g_lw_variant == 12 || (g_lw_variant == 0 && sizeof(F) == 8)) && ncol % VBB == 0 &&
+            launch_scan_bb16<F,VBB>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                    sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
+            return 0;
         const bool four = (g_lw_variant == 9) || (g_lw_variant != 8 && sizeof(F) == 4);
         if (four && ncol % (2*VBB) == 0 &&
             launch_scan_bb<F,2*VBB,4>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,

@@ -121,12 +121,20 @@ def test_fused_broadband_solvers_sum_gpoints_in_order(dt, top_at_1, hip_f64, hip
     stored = [be.to_numpy(be.sum_broadband(x)) for x in solve(slice(None), False)]
     be.set_broadband_min_groups(1)
     try:
+        # the other tilings of the fused LW form (two waves, four waves, 16 x 4 lanes) against the stored fluxes
+        for lwv in (8, 9, 12):
+            be.set_variant(lw=lwv)
+            alt = [be.to_numpy(x) for x in solve(slice(None), True)]
+            for name, a_, c_ in zip(names[:2], alt[:2], stored[:2]):
+                assert cases.rel_err(a_, c_) <= (1e-13 if dt == "f64" else 1e-5), (name, lwv)
+        be.set_variant(lw=0)
         fused = [be.to_numpy(x) for x in solve(slice(None), True)]
         seq = None
         for ig in range(ngpt):
             one = [be.to_numpy(x) for x in solve(slice(ig, ig+1), True)]
             seq = one if seq is None else [a_ + b_ for a_, b_ in zip(seq, one)]
     finally:
+        be.set_variant(lw=0)
         be.set_broadband_min_groups(512)
     for name, a_, b_, c_ in zip(names, fused, seq, stored):
         assert a_.shape == b_.shape == (nlay+1, ncol) and a_.dtype == b_.dtype
