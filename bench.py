@@ -25,16 +25,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic words per (column, g-point) at nlay layers -- SURVEY.md section 8(d), DESIGN.md section 5
-def algo_words(nlay, ngpt, broadband):
+def algo_words(nlay, ngpt, broadband, g_zero):
     nlev = nlay + 1
+    nsw = 2 if g_zero else 3        # clear sky: the all-zero asymmetry array is neither written nor read
     if broadband:       # fused form: the solvers keep the g-point sums on chip and store (ncol, nlev) arrays once
         return dict(
             lw_gas_optics=nlay,
             lw_planck=2*nlay + 1 + 2,
             lw_solver=3*nlay + 1 + 2 + 2*nlev/ngpt,
             lw_reduce=0,
-            sw_gas_optics=3*nlay + 1,
-            sw_solver=3*nlay + 3 + 3*nlev/ngpt,
+            sw_gas_optics=nsw*nlay + 1,
+            sw_solver=nsw*nlay + 3 + 3*nlev/ngpt,
             sw_reduce=0)
     return dict(
         lw_gas_optics=nlay,                              # tau
@@ -198,7 +199,7 @@ def main():
     if rank == 0:
         S = np_dtype().itemsize
         ms = solver.stage_ms()
-        words = algo_words(args.nlay, args.ngpt, args.broadband)
+        words = algo_words(args.nlay, args.ngpt, args.broadband, solver.g_zero and args.broadband)
         units = args.ncol * args.ngpt
         kernels = {}
         for st, w in words.items():

@@ -50,6 +50,11 @@ class Optical_props_arry_gpu : public Optical_props_gpu
         virtual void delta_scale(const Array_gpu<Float,3>& forward_frac=Array_gpu<Float,3>()) = 0;
         virtual int get_ncol() const = 0;
         virtual int get_nlay() const = 0;
+        // Addition: clear-sky gas optics produce g == 0 everywhere. set_g_zero() records that instead of writing the
+        // array; get_g_or_null() hands nullptr to kernels that take "no asymmetry" natively (rrx_sw_solver_2stream);
+        // any other access through get_g() fills the array with zeros first, so the reference semantics are unchanged.
+        virtual void set_g_zero() {}
+        virtual const Float* get_g_or_null() const { return get_g().ptr(); }
 };
 
 class Optical_props_1scl_gpu : public Optical_props_arry_gpu
@@ -77,14 +82,18 @@ class Optical_props_2str_gpu : public Optical_props_arry_gpu
         int get_nlay() const { return tau.dim(2); }
         Array_gpu<Float,3>& get_tau() { return tau; }
         Array_gpu<Float,3>& get_ssa() { return ssa; }
-        Array_gpu<Float,3>& get_g  () { return g; }
+        Array_gpu<Float,3>& get_g  () { materialize_g(); return g; }
         const Array_gpu<Float,3>& get_tau() const { return tau; }
         const Array_gpu<Float,3>& get_ssa() const { return ssa; }
-        const Array_gpu<Float,3>& get_g  () const { return g; }
+        const Array_gpu<Float,3>& get_g  () const { materialize_g(); return g; }
         void delta_scale(const Array_gpu<Float,3>& forward_frac=Array_gpu<Float,3>());
+        void set_g_zero() { g_zero = true; }
+        const Float* get_g_or_null() const { return g_zero ? nullptr : g.ptr(); }
     private:
+        void materialize_g() const;
         Array_gpu<Float,3> tau;
         Array_gpu<Float,3> ssa;
-        Array_gpu<Float,3> g;
+        mutable Array_gpu<Float,3> g;
+        mutable bool g_zero = false;
 };
 #endif

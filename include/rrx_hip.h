@@ -74,7 +74,8 @@ int rrx_lw_solver_noscat##SFX( \
         RrxBool do_broadband, F* flux_up_loc, F* flux_dn_loc, \
         RrxBool do_jacobians, const F* sfc_src_jac, F* flux_up_jac, void* stream); \
 /* sw_solver_2stream: launchers.cu:289-447. mu0 is (ncol) as on the reference GPU path; sfc_alb_dir is indexed \
-   per g-point (Fortran semantics); has_dif_bc and do_broadband are honoured. */ \
+   per g-point (Fortran semantics); has_dif_bc and do_broadband are honoured. g may be NULL = asymmetry \
+   identically zero (what clear-sky gas optics produce): same fluxes as with an array of zeros, which is not read. */ \
 int rrx_sw_solver_2stream##SFX( \
         int ncol, int nlay, int ngpt, RrxBool top_at_1, \
         const F* tau, const F* ssa, const F* g, const F* mu0, \
@@ -141,7 +142,8 @@ int rrx_compute_planck_source##SFX( \
         F temp_ref_min, F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
         F* sfc_src, F* lay_src, F* lev_src, F* sfc_src_jac, void* stream); \
 /* fused SW gas optics used by Gas_optics_rrtmgp_gpu (tau_abs + tau_rayleigh + combine in one pass, tau/ssa/g \
-   written once; same arithmetic as the three launchers above called in sequence on a zeroed tau) */ \
+   written once; same arithmetic as the three launchers above called in sequence on a zeroed tau). g may be NULL: \
+   the asymmetry parameter of the gas optics is identically zero and is then not written */ \
 int rrx_gas_optics_sw_fused##SFX( \
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
         int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \

@@ -496,7 +496,7 @@ tau_absorption_kernel(
                     const F tt = t[u] + ray;
                     tau[o] = tt;
                     ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
-                    g[o] = F(0.);
+                    if (g != nullptr) g[o] = F(0.);
                 }
             }
         }

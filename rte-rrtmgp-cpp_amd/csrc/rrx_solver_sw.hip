@@ -106,7 +106,7 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // BB (broadband): the workgroup walks over ALL g-points of its columns and keeps the g-point sums of the three fluxes
 // on chip (up and dn in LDS, dir in registers), added in g-point order like sum_broadband does on stored per-g-point
 // fluxes, so the same bits; flux_up/dn/dir are then (ncol, nlev) arrays.
-template<typename F, int V, int K, int W, bool BB = false>
+template<typename F, int V, int K, int W, bool BB = false, bool GZ = false>
 __global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
@@ -194,7 +194,13 @@ sw_2stream_scan_kernel(
         }
         Vec<F,V> tv = load_cols<F,V>(tau + off);
         const Vec<F,V> wv = load_cols<F,V>(ssa + off);
-        const Vec<F,V> gv = load_cols<F,V>(g   + off);
+        Vec<F,V> gv;
+        if constexpr (GZ)                                  // asymmetry identically zero (clear-sky gas optics): g is not read
+        {
+            #pragma unroll
+            for (int v=0; v<V; ++v) gv.v[v] = F(0.);
+        }
+        else gv = load_cols<F,V>(g + off);
         // (V == 1: the tie sits ahead of the evaluation loop, V > 1: on each column's tau. Same dependence, but the
         //  register allocator lands differently: measured fp64 6.3 vs 8.3 ms and fp32 6.4 vs 4.4 ms, tools/ab_sw.sh)
         if constexpr (BB && V == 1)
@@ -591,9 +597,14 @@ bool launch_scan_bb(hipStream_t st,
 {
     const dim3 grid(ceil_div(ncol, 2*CL*V), 1);
     const int need = ceil_div(nlay+1, LL*2);
-#define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK,2,true><<<grid, 256, 0, st>>>( \
-        ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-        flux_up, flux_dn, flux_dir, g_sync_waves); return true; }
+#define RRX_SW_K(KK) if (need <= KK) { \
+        if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            flux_up, flux_dn, flux_dir, g_sync_waves); \
+        else sw_2stream_scan_kernel<F,V,KK,2,true,false><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            flux_up, flux_dn, flux_dir, g_sync_waves); \
+        return true; }
     RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12)
 #undef RRX_SW_K
     return false;
@@ -622,6 +633,16 @@ int sw_solver_2stream_impl(
         if (launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                   inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
+    }
+
+    // g == nullptr (asymmetry identically zero) is native to the fused broadband kernels only: the other forms read zeros
+    F* gzeros = nullptr;
+    if (g == nullptr)
+    {
+        const size_t nb = size_t(ncol)*nlay*ngpt*sizeof(F);
+        if (hipMallocAsync(reinterpret_cast<void**>(&gzeros), nb, st) != hipSuccess || hipMemsetAsync(gzeros, 0, nb, st) != hipSuccess)
+            throw std::runtime_error("workspace allocation failed");
+        g = gzeros;
     }
 
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
@@ -672,6 +693,7 @@ int sw_solver_2stream_impl(
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dr, flux_dir_loc);
         (void)hipFreeAsync(ws, st);
     }
+    if (gzeros != nullptr) (void)hipFreeAsync(gzeros, st);
     RRX_CATCH("rrx_sw_solver_2stream")
 }
 

@@ -332,6 +332,8 @@ class HipKernels:
         self._c("subset_cols", ncol_full, nrest, col_s, ncol_sub, arr, out)
         return out
 
+    supports_null_g = True      # gas_optics_sw_fused / sw_solver_2stream accept g = None (asymmetry identically zero)
+
     def set_broadband_min_groups(self, n):
         """column groups needed before do_broadband takes the fused one-kernel form (default 512; 1 = always)"""
         self.lib.call("rrx_set_broadband_min_groups", int(n))

@@ -445,7 +445,8 @@ void Gas_optics_rrtmgp_gpu::compute_gas_taus(
                 kminor_start_lower_gpu.ptr(), kminor_start_upper_gpu.ptr(),
                 st.tropo.ptr(), st.col_mix.ptr(), st.fmajor.ptr(), st.fminor.ptr(), play.ptr(), tlay.ptr(), st.col_gas.ptr(), col_dry.ptr(),
                 st.jeta.ptr(), st.jtemp.ptr(), st.jpress.ptr(), krayl_gpu.ptr(),
-                optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), optical_props->get_g().ptr());
+                optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), static_cast<Float*>(nullptr));
+        optical_props->set_g_zero();          // g == 0: not written; materialised on the first get_g() (clouds, output)
     }
     else
     {

@@ -41,6 +41,13 @@ Optical_props_2str_gpu::Optical_props_2str_gpu(const int ncol, const int nlay, c
     Optical_props_arry_gpu(op), tau({ncol, nlay, this->get_ngpt()}), ssa({ncol, nlay, this->get_ngpt()}), g({ncol, nlay, this->get_ngpt()})
 {}
 
+void Optical_props_2str_gpu::materialize_g() const
+{
+    if (!g_zero) return;
+    Gas_optics_rrtmgp_kernels_cuda::zero_array(g.dim(1), g.dim(2), g.dim(3), g.ptr());
+    g_zero = false;
+}
+
 void Optical_props_2str_gpu::delta_scale(const Array_gpu<Float,3>& forward_frac)
 {
     if (forward_frac.size() > 0) throw std::runtime_error("delta_scale with a forward fraction is not on the reference's path");

@@ -11,6 +11,8 @@ Mirrors, call for call, what the reference's host classes do around the kernel l
 The backend is either HipKernels (product path, torch CUDA tensors) or, in tests only, a CPU checker from
 oracle/oracle_py.py (numpy). This module never imports the oracle.
 """
+import os
+
 import numpy as np
 
 from ._ffi import BoolArg
@@ -97,8 +99,12 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
 
     if fused_gas is None:
         fused_gas = hasattr(be, "gas_optics_sw_fused")
+    # clear sky: the asymmetry parameter of the gas optics is identically zero; the HIP entry points take "no g array"
+    # natively (nothing written by the gas optics, nothing read by the solver)
+    g_zero = bool(fused_gas and cloud_lut is None and getattr(be, "supports_null_g", False))
     if fused_gas:
-        tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol)); g = be.empty((ngpt, nlay, ncol))
+        tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol))
+        g = None if g_zero else be.empty((ngpt, nlay, ncol))
         be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
     else:
         tau_abs = be.zeros((ngpt, nlay, ncol))
@@ -128,7 +134,7 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
     flux_net = be.net_broadband_precalc(flux_dn, flux_up)
     out = dict(flux_up=flux_up, flux_dn=flux_dn, flux_dn_dir=flux_dir, flux_net=flux_net)
     if keep:
-        out.update(tau=tau, ssa=ssa, g=g, toa_src=toa_src, gpt_flux_up=r.get("flux_up"),
+        out.update(tau=tau, ssa=ssa, g=be.zeros((ngpt, nlay, ncol)) if g is None else g, toa_src=toa_src, gpt_flux_up=r.get("flux_up"),
                    gpt_flux_dn=r.get("flux_dn"), gpt_flux_dir=r.get("flux_dir"))
     return out
 
@@ -150,6 +156,7 @@ class ResidentSolver:
         self.streams = [torch.cuda.Stream(device=be.device), torch.cuda.Stream(device=be.device)] if overlap else None
         self.be, self.kd_lw, self.kd_sw, self.atm = be, kd_lw, kd_sw, atm
         self.do_broadband = do_broadband
+        self.g_zero = bool(int(os.environ.get("RRX_G_ZERO", "1")))     # clear sky: g == 0 is neither written nor read
         ncol, nlay = atm.ncol, atm.nlay
         ng_l, ng_s = kd_lw.ngpt, kd_sw.ngpt
         e = be.empty
@@ -232,17 +239,18 @@ class ResidentSolver:
                 be.net_broadband_precalc(F[1], F[0], out=F[2])
                 mark("lw_reduce", True)
             else:
-                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], buf["g"])
+                gbuf = None if self.g_zero else buf["g"]      # clear sky: the asymmetry parameter is identically zero
+                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
                 toa = be.spread_col(ncol, kd.solar_source)
                 be.scaling_to_subset(toa, atm.tsi_scaling)
                 mark("sw_gas_optics", True)
                 mark("sw_solver")
                 if self.do_broadband:
-                    be._c("sw_solver_2stream", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), buf["tau"], buf["ssa"], buf["g"], atm.mu0,
+                    be._c("sw_solver_2stream", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), buf["tau"], buf["ssa"], gbuf, atm.mu0,
                           self.alb_dir, self.alb_dif, toa, None, None, None, BoolArg(False), None,
                           BoolArg(True), F[3], F[4], F[5])
                 else:
-                    be.sw_solver_2stream_into(atm.top_at_1, buf["tau"], buf["ssa"], buf["g"], atm.mu0, self.alb_dir, self.alb_dif,
+                    be.sw_solver_2stream_into(atm.top_at_1, buf["tau"], buf["ssa"], gbuf, atm.mu0, self.alb_dir, self.alb_dif,
                                               toa, buf["gpt_up"], buf["gpt_dn"], buf["gpt_dir"])
                 mark("sw_solver", True)
                 mark("sw_reduce")

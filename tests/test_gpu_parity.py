@@ -173,6 +173,28 @@ def test_columns_in_different_regimes_within_one_wavefront(kind, hip_f64, oracle
         assert cases.rel_err(h[k], o[k]) <= (1e-7 if kind == "sw" and k.startswith("flux") else 1e-9), k
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
+    """g = NULL (asymmetry identically zero: clear-sky gas optics) gives the same bits as an array of zeros, in the
+    per-g-point form (zeros workspace), the workspace broadband form and the fused broadband form (native)."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    rng = np.random.default_rng(21)
+    ngpt, nlay, ncol = 12, 140, 40
+    tau = 10.0**rng.uniform(-5, 1.5, (ngpt, nlay, ncol)); ssa = rng.uniform(0, 1, tau.shape)
+    e2 = rng.uniform(.5, 1, (ngpt, ncol)); mu0 = rng.uniform(.1, 1, ncol)
+    up = be.asarray
+    zero = be.zeros(tau.shape)
+    for bb, mg in ((False, 512), (True, 1 << 30), (True, 1)):
+        be.set_broadband_min_groups(mg)
+        try:
+            a = be.sw_solver_2stream(False, up(tau), up(ssa), zero, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=bb)
+            b = be.sw_solver_2stream(False, up(tau), up(ssa), None, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=bb)
+        finally:
+            be.set_broadband_min_groups(512)
+        for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert np.array_equal(be.to_numpy(a[k]), be.to_numpy(b[k])), (k, bb, mg)
+
+
 def test_lw_multi_angle_and_incident_flux(hip_f64, oracle_f64):
     rng = np.random.default_rng(5)
     ngpt, nlay, ncol = 16, 33, 50
