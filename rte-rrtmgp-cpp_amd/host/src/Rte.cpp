@@ -95,7 +95,9 @@ void Rte_sw_gpu::rte_sw(
 
     Rte_solver_kernels_cuda::sw_solver_2stream(
             ncol, nlay, ngpt, top_at_1,
-            optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), optical_props->get_g_or_null(),
+            optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(),
+            // "no g" is native to the fused broadband solver; the per-g-point forms read an array (zeros materialised here)
+            do_broadband ? optical_props->get_g_or_null() : static_cast<const Float*>(optical_props->get_g().ptr()),
             mu0.ptr(),
             sfc_alb_dir_gpt.ptr(), sfc_alb_dif_gpt.ptr(),
             inc_flux_dir.ptr(),

@@ -239,7 +239,8 @@ class ResidentSolver:
                 be.net_broadband_precalc(F[1], F[0], out=F[2])
                 mark("lw_reduce", True)
             else:
-                gbuf = None if self.g_zero else buf["g"]      # clear sky: the asymmetry parameter is identically zero
+                # clear sky: the asymmetry parameter is identically zero; the fused broadband solver takes "no g" natively
+                gbuf = None if (self.g_zero and self.do_broadband) else buf["g"]
                 be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
                 toa = be.spread_col(ncol, kd.solar_source)
                 be.scaling_to_subset(toa, atm.tsi_scaling)
