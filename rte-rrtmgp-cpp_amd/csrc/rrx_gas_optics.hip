@@ -318,7 +318,10 @@ tau_absorption_kernel(
 
     // G g-points at a time: all LUT gathers of the group are issued before the first use, so one memory round trip is
     // paid per group instead of per g-point (a g-point-at-a-time loop is latency-bound: 78 % of wave cycles in s_waitcnt).
-    constexpr int G = 4;
+#ifndef RRX_GO_G
+#define RRX_GO_G 4
+#endif
+    constexpr int G = RRX_GO_G;
     // contributors requested with the major words: 2 in the fp64 LW forms (register room), 1 otherwise (measured, tools/ab_build.sh)
     constexpr int NPRE = (sizeof(F) == 8) ? ((MODE == 1) ? NPRE_F64 : NPRE_F64 + 1) : NPRE_F32;
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
