@@ -195,6 +195,37 @@ def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
             assert np.array_equal(be.to_numpy(a[k]), be.to_numpy(b[k])), (k, bb, mg)
 
 
+@pytest.mark.parametrize("ncol,nlay,ngpt", [(1, 1, 1), (3, 2, 5), (65, 143, 4), (64, 144, 3), (33, 271, 3), (33, 272, 3), (10, 300, 2)])
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_solver_shapes_at_the_tiling_boundaries(ncol, nlay, ngpt, top_at_1, hip_f64, oracle_f64):
+    """Layer counts around the K steps of the scan tilings (143/144: K = 9 -> 12 for two waves; 271/272: last scan size ->
+    serial fallback), single cells, ragged column counts: per-g-point and broadband forms against the oracle."""
+    rng = np.random.default_rng(1000*nlay + ncol)
+    tau = 10.0**rng.uniform(-4, 1.2, (ngpt, nlay, ncol)); ssa = rng.uniform(0, 1, tau.shape); g = rng.uniform(0, .9, tau.shape)
+    lay = rng.uniform(5, 40, tau.shape); lev = rng.uniform(5, 40, (ngpt, nlay+1, ncol))
+    e2 = rng.uniform(.5, 1, (ngpt, ncol)); mu0 = rng.uniform(.1, 1, ncol)
+    res = []
+    for be in (hip_f64, oracle_f64):
+        up = be.asarray
+        sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+        l = be.lw_solver_noscat(top_at_1, sec, w, up(tau), up(lay), up(lev), up(e2), up(e2*20))
+        s_ = be.sw_solver_2stream(top_at_1, up(tau), up(ssa), up(g), up(mu0), up(e2*.5), up(e2*.4), up(e2*3))
+        res.append([be.to_numpy(x) for x in (l["flux_up"], l["flux_dn"], s_["flux_up"], s_["flux_dn"], s_["flux_dir"])])
+    for name, a_, b_ in zip(("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dir"), *res):
+        assert cases.rel_err(a_, b_) <= (1e-10 if name.startswith("lw") else 1e-7), name
+    hip_f64.set_broadband_min_groups(1)
+    try:
+        up = hip_f64.asarray
+        sec = hip_f64.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+        lb = hip_f64.lw_solver_noscat(top_at_1, sec, w, up(tau), up(lay), up(lev), up(e2), up(e2*20), do_broadband=True)
+        sb = hip_f64.sw_solver_2stream(top_at_1, up(tau), up(ssa), up(g), up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=True)
+    finally:
+        hip_f64.set_broadband_min_groups(512)
+    bb = [hip_f64.to_numpy(x) for x in (lb["flux_up"], lb["flux_dn"], sb["flux_up"], sb["flux_dn"], sb["flux_dir"])]
+    for name, a_, b_ in zip(("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dir"), bb, res[1]):
+        assert cases.rel_err(a_, b_.sum(axis=0)) <= (1e-10 if name.startswith("lw") else 1e-7), name
+
+
 def test_lw_multi_angle_and_incident_flux(hip_f64, oracle_f64):
     rng = np.random.default_rng(5)
     ngpt, nlay, ncol = 16, 33, 50
