@@ -700,7 +700,10 @@ planck_source_kernel(
     F b_lay = 0, b_lev = 0, b_levp = 0, b_sfc = 0, b_sfc2 = 0;
 
     // Planck fractions of up to PG g-points of one cell: all 8*PG gathers are issued before the first use
-    constexpr int PG = 4;
+    // batch of the per-lane (not shared-cell) gathers: small on purpose -- at 2 (fp64: 164 VGPRs) / 1 (fp32: 118) a third
+    // workgroup fits each CU, whose phases interleave with the others': 3.26 -> 2.63 ms (fp32 1.96 -> 1.74), and still
+    // faster than 4 when every wavefront takes this path (3.35 against 3.63 ms)
+    constexpr int PG = (sizeof(F) == 8) ? 2 : 1;
     auto fractions = [&](CellInterp<F>& ci, int& cur, const size_t cell_idx, const int itr, const int ig_first, const int gend, const int slot,
                          const int ig0)
     {
