@@ -144,7 +144,7 @@ __device__ inline MinorIndex build_minor_index(
 #ifndef RRX_GO_NPRE32
 #define RRX_GO_NPRE32 1
 #endif
-constexpr int NPRE_F64 = RRX_GO_NPRE, NPRE_F32 = RRX_GO_NPRE32;   // minor contributors requested in the first batch of a g-point group
+[[maybe_unused]] constexpr int NPRE_F64 = RRX_GO_NPRE, NPRE_F32 = RRX_GO_NPRE32;   // minor contributors requested in the first batch of a g-point group
 constexpr int SL = 6;        // minor contributors of a chunk held in registers; further ones take a slower loop
 struct Slots { int lo[SL], hi[SL], koff[SL], mf[SL]; };
 
@@ -318,12 +318,16 @@ tau_absorption_kernel(
 
     // G g-points at a time: all LUT gathers of the group are issued before the first use, so one memory round trip is
     // paid per group instead of per g-point (a g-point-at-a-time loop is latency-bound: 78 % of wave cycles in s_waitcnt).
-#ifndef RRX_GO_G
-#define RRX_GO_G 4
-#endif
+    // fp64: 2 g-points per batch and no contributor in the first batch keep the kernel at <= 162 VGPRs = 3 waves per SIMD,
+    // which beats the deeper batches at 2 waves (LW 4.26 -> 4.16 ms, SW 5.87 -> 5.78 ms); fp32 has the registers for
+    // 4 g-points + 1 contributor at 3 waves (tools/ab_build.sh, RRX_GO_G / RRX_GO_NPRE / RRX_GO_NPRE32 override)
+#ifdef RRX_GO_G
     constexpr int G = RRX_GO_G;
-    // contributors requested with the major words: 2 in the fp64 LW forms (register room), 1 otherwise (measured, tools/ab_build.sh)
-    constexpr int NPRE = (sizeof(F) == 8) ? ((MODE == 1) ? NPRE_F64 : NPRE_F64 + 1) : NPRE_F32;
+    constexpr int NPRE = (sizeof(F) == 8) ? NPRE_F64 : NPRE_F32;
+#else
+    constexpr int G = (sizeof(F) == 8) ? 2 : 4;
+    constexpr int NPRE = (sizeof(F) == 8) ? 0 : 1;
+#endif
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
     {
         int igs[G];
