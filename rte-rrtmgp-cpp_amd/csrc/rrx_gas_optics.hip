@@ -318,15 +318,17 @@ tau_absorption_kernel(
 
     // G g-points at a time: all LUT gathers of the group are issued before the first use, so one memory round trip is
     // paid per group instead of per g-point (a g-point-at-a-time loop is latency-bound: 78 % of wave cycles in s_waitcnt).
-    // fp64: 2 g-points per batch and no contributor in the first batch keep the kernel at <= 162 VGPRs = 3 waves per SIMD,
-    // which beats the deeper batches at 2 waves (LW 4.26 -> 4.16 ms, SW 5.87 -> 5.78 ms); fp32 has the registers for
-    // 4 g-points + 1 contributor at 3 waves (tools/ab_build.sh, RRX_GO_G / RRX_GO_NPRE / RRX_GO_NPRE32 override)
+    // Batch shape, measured per form at C4 (alternating builds on one box, tools/ab_build.sh; differences are 2-4 %):
+    //   fp64 SW fused form: 2 g-points, no contributor in the first batch  -> 157 VGPRs, 3 waves per SIMD (5.68 vs 5.80 ms)
+    //   fp64 LW forms:      4 g-points + 2 contributors in the first batch -> 2 waves per SIMD          (4.30 vs 4.43 ms)
+    //   fp32:               4 g-points + 1 contributor, 3 waves per SIMD
+    // RRX_GO_G / RRX_GO_NPRE / RRX_GO_NPRE32 override all of them for A/B builds.
 #ifdef RRX_GO_G
     constexpr int G = RRX_GO_G;
     constexpr int NPRE = (sizeof(F) == 8) ? NPRE_F64 : NPRE_F32;
 #else
-    constexpr int G = (sizeof(F) == 8) ? 2 : 4;
-    constexpr int NPRE = (sizeof(F) == 8) ? 0 : 1;
+    constexpr int G = (sizeof(F) == 8 && MODE == 1) ? 2 : 4;
+    constexpr int NPRE = (sizeof(F) == 8) ? ((MODE == 1) ? 0 : 2) : 1;
 #endif
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
     {
