@@ -8,7 +8,9 @@ Columns shard over ranks (one process per GPU, weak scaling: --ncol columns PER 
 all-gather of the packed broadband fluxes (7 x nlev x ncol words per rank) at the end of each step.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 8 --scaling strong     # BASELINE C4 as stated: 16 384 columns sharded over the 8 GPUs
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant kernel, live HIP-event
 timing on the launch stream) and `cpu_baseline` (the oracle, a scalar CPU port, on a bounded column sample).
@@ -116,12 +118,42 @@ def cpu_baseline(args, kd_lw0, kd_sw0, be=None):
     return out
 
 
+def launch_command(argv, gpus, port=None):
+    """What `bench.py --gpus N` (N > 1) runs when it was not started by torch.distributed.run: the documented launcher
+    as a CHILD process, one rank per GPU. Nothing in this process has touched the GPU (or imported torch) at that point."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def global_columns(args, world):
+    """Total column count of the job: weak scaling keeps --ncol columns PER GPU, strong scaling shards --ncol over the ranks."""
+    return args.ncol * world if args.scaling == "weak" else args.ncol
+
+
+def local_atmosphere(args, nbnd, rank, world):
+    """This rank's column range [start, stop) of the job's global synthetic atmosphere (sharding.column_range) and its
+    host-side slice. Column c of the job is the same column whatever the number of ranks."""
+    from rte_rrtmgp_cpp_amd import synthetic, sharding
+    ntot = global_columns(args, world)
+    s, e = sharding.column_range(rank, world, ntot)
+    full = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234)
+    return (s, e), (full if world == 1 else sharding.shard_atmosphere(full, rank, world))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ncol", type=int, default=128*128, help="columns PER GPU (C4 = 128 x 128)")
+    ap.add_argument("--ncol", type=int, default=128*128, help="columns per GPU (weak scaling) or in total (strong); C4 = 128 x 128")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --ncol columns on every GPU; strong: --ncol columns sharded over the GPUs (BASELINE C4 on 8 GPUs = 2048 each)")
+    ap.add_argument("--dry-run", action="store_true", help="print the launch command of a multi-GPU run and exit")
     ap.add_argument("--nlay", type=int, default=140)
     ap.add_argument("--ngpt", type=int, default=256)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -139,10 +171,22 @@ def main():
     args = ap.parse_args()
     args.broadband = (args.flux_mode == "broadband" or args.broadband) and not args.per_gpoint
 
+    # `python bench.py --gpus N` on its own: become the launcher of N ranks. This happens before torch is imported, so this
+    # process never initialises the GPU; the ranks are children (never an exec of a process that holds a GPU context).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = launch_command(sys.argv[1:], args.gpus)
+        if args.dry_run:
+            print(" ".join(cmd)); return 0
+        import subprocess
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return subprocess.run(cmd, env=env).returncode
+    if args.dry_run:
+        print(" ".join([sys.executable, os.path.abspath(__file__)] + sys.argv[1:])); return 0
+
     import torch
     import torch.distributed as dist
     import rte_rrtmgp_cpp_amd as R
-    from rte_rrtmgp_cpp_amd import synthetic, pipeline
+    from rte_rrtmgp_cpp_amd import synthetic, pipeline, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,19 +207,19 @@ def main():
     kd_lw0 = synthetic.make_kdist("lw", ngpt=args.ngpt, nbnd=nbnd)
     kd_sw0 = synthetic.make_kdist("sw", ngpt=args.ngpt, nbnd=nbnd)
     kd_lw, kd_sw = be.upload_kdist(kd_lw0), be.upload_kdist(kd_sw0)
-    # rank r owns global columns [r*ncol, (r+1)*ncol): different seed offset per rank, same generator
-    atm0 = synthetic.make_atmosphere(args.ncol, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234 + rank)
+    # rank r owns the contiguous column range sharding.column_range(r, world, ntot) of ONE global atmosphere
+    ntot = global_columns(args, world)
+    (col_s, col_e), atm0 = local_atmosphere(args, nbnd, rank, world)
+    ncol_local = col_e - col_s
     atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
     solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap)
-    gathered = None
-    if world > 1 and not args.no_gather:
-        shp = tuple(solver.fluxes.shape)
-        gathered = torch.empty((world*shp[0],) + shp[1:], dtype=solver.fluxes.dtype, device=device)
+    do_gather = world > 1 and not args.no_gather
+    gatherer = sharding.FluxGatherer(ntot, solver.fluxes) if do_gather else None
 
     def one_step():
         F = solver.step()
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, F)
+        if gatherer is not None:
+            gatherer.gather(F)          # the one collective of the path (tests/test_dist_gloo.py runs this code on gloo)
 
     for _ in range(args.warmup):
         one_step()
@@ -200,7 +244,7 @@ def main():
         S = np_dtype().itemsize
         ms = solver.stage_ms()
         words = algo_words(args.nlay, args.ngpt, args.broadband, solver.g_zero and args.broadband)
-        units = args.ncol * args.ngpt
+        units = ncol_local * args.ngpt
         kernels = {}
         for st, w in words.items():
             gbs = w * units * S / (max(ms[st], 1e-6)*1e-3) / 1e9
@@ -210,15 +254,15 @@ def main():
         finite = bool(torch.isfinite(solver.fluxes).all().item())
         out = {
             "metric": "columns/sec (LW+SW full solve, 140 lay x 256 gpt)",
-            "value": round(args.ncol * world * args.steps / dt, 1),
+            "value": round(ntot * args.steps / dt, 1),
             "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C4 synthetic {args.ncol} columns/GPU x {args.nlay} layers x {args.ngpt} g-points, "
+            "config": {"workload": f"C4 synthetic {ncol_local} columns/GPU ({ntot} in total) x {args.nlay} layers x {args.ngpt} g-points, "
                                    f"LW+SW clear-sky, RCEMIP profile, synthetic k-distribution (real shapes)",
-                       "columns_per_gpu": args.ncol, "nlay": args.nlay, "ngpt": args.ngpt,
+                       "columns_per_gpu": ncol_local, "columns_total": ntot, "nlay": args.nlay, "ngpt": args.ngpt,
                        "flux_mode": "broadband (do_broadband solvers, g-point sums on chip)" if args.broadband
                                     else "per-g-point fluxes + sum_broadband",
                        "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
@@ -236,4 +280,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

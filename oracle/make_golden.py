@@ -139,6 +139,35 @@ def random_solver_case(dtype, top_at_1, ncol, nlay, ngpt, seed):
     return out
 
 
+def glue_case(dtype, top_at_1, seed):
+    """Stand-alone launchers around the solvers: the three apply_BC overloads, the two transposes, and the LW solver
+    with a non-zero incident flux (which the reference's CUDA text halves: /(2 pi w) at rte_solver_kernels.cu:160, then
+    *(pi w) at :189-190 -- SURVEY Q3; the fixture pins that factor)."""
+    ref = O.CpuKernels("ref", dtype)
+    rng = np.random.default_rng(seed)
+    ncol, nlay, ngpt = 5, 7, 6
+    out = {}
+    base = rng.uniform(1., 2., (ngpt, nlay+1, ncol)).astype(dtype)
+    inc = rng.uniform(0., 5., (ngpt, ncol)).astype(dtype)
+    fac = rng.uniform(0.1, 1., ncol).astype(dtype)
+    out.update(bc_base=base, bc_inc=inc, bc_factor=fac,
+               bc_0=ref.apply_BC(nlay, top_at_1, base.copy()),
+               bc_gpt=ref.apply_BC(nlay, top_at_1, base.copy(), inc),
+               bc_fac=ref.apply_BC(nlay, top_at_1, base.copy(), inc, fac))
+    a3 = rng.uniform(-1., 1., (3, 4, 5)).astype(dtype); a2 = rng.uniform(-1., 1., (7, 3)).astype(dtype)
+    out.update(ro_a3=a3, ro_a2=a2, ro_321=ref.reorder123x321(a3), ro_21=ref.reorder12x21(a2))
+    shp = (ngpt, nlay, ncol)
+    tau = (10.0**rng.uniform(-3, 1, shp)).astype(dtype)
+    lay = rng.uniform(5., 40., shp).astype(dtype); lev = rng.uniform(5., 40., (ngpt, nlay+1, ncol)).astype(dtype)
+    emis = rng.uniform(0.8, 1.0, (ngpt, ncol)).astype(dtype); ssrc = rng.uniform(5., 40., (ngpt, ncol)).astype(dtype)
+    sec = ref.lw_secants_array(ncol, ngpt, 1, 4, ref.asarray(pipeline.GAUSS_DS))
+    fl = ref.lw_solver_noscat(top_at_1, sec, ref.asarray(np.array([1.0])), tau, lay, lev, emis, ssrc, inc_flux=inc)
+    out.update(lw_tau=tau, lw_lay_src=lay, lw_lev_src=lev, lw_emis=emis, lw_sfc_src=ssrc, lw_inc=inc,
+               lw_inc_flux_up=fl["flux_up"], lw_inc_flux_dn=fl["flux_dn"])
+    out["meta"] = np.array([ncol, nlay, int(top_at_1), seed])
+    return out
+
+
 def main():
     O.build(ref=True)
     os.makedirs(GOLDEN, exist_ok=True)
@@ -151,6 +180,13 @@ def main():
                     (f"random_{tag}_top{int(top)}", random_solver_case(dtype, top, 5, 19, 8, 11 + int(top)))):
                 path = os.path.join(GOLDEN, name + ".npz")
                 np.savez_compressed(path, **case)
+                total += os.path.getsize(path)
+                print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+    if True:
+        for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            for top in (False, True):
+                path = os.path.join(GOLDEN, f"glue_{tag}_top{int(top)}.npz")
+                np.savez_compressed(path, **glue_case(dtype, top, 21 + int(top)))
                 total += os.path.getsize(path)
                 print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
     # degenerate shape: 1 column x 4 layers

@@ -241,6 +241,32 @@ class CpuKernels:
         self.lib.call(self._nm("rte_net_broadband_precalc", "ref_net_broadband_precalc"), ncol, nlev, flux_dn, flux_up, out)
         return out
 
+    # ---- stand-alone boundary conditions and transposes (reference kernel text only: the CPU path has no such entry) ----
+    def apply_BC(self, nlay, top_at_1, flux_dn, inc_flux=None, factor=None):
+        assert not self.is_oracle, "apply_BC_* are commented out of include/rrtmgp_kernels.h: only the CUDA text has them"
+        ngpt, nlev, ncol = flux_dn.shape
+        if inc_flux is None:
+            self.lib.call("ref_apply_BC_0", ncol, nlay, ngpt, BoolArg(top_at_1), flux_dn)
+        elif factor is None:
+            self.lib.call("ref_apply_BC_gpt", ncol, nlay, ngpt, BoolArg(top_at_1), inc_flux, flux_dn)
+        else:
+            self.lib.call("ref_apply_BC_factor", ncol, nlay, ngpt, BoolArg(top_at_1), inc_flux, factor, flux_dn)
+        return flux_dn
+
+    def reorder123x321(self, arr_in):
+        assert not self.is_oracle
+        ni, nj, nk = arr_in.shape          # memory: k fastest (C order of shape (ni, nj, nk)) = arr_in(ik + ij*nk + ii*nj*nk)
+        out = self.empty((nk, nj, ni))     # memory: i fastest
+        self.lib.call("ref_reorder123x321", ni, nj, nk, arr_in, out)
+        return out
+
+    def reorder12x21(self, arr_in):
+        assert not self.is_oracle
+        ni, nj = arr_in.shape
+        out = self.empty((nj, ni))
+        self.lib.call("ref_reorder12x21", ni, nj, arr_in, out)
+        return out
+
     def sum_byband(self, gpt_flux, band_lims):
         assert self.is_oracle, "the reference CUDA by-band kernels are buggy (SURVEY Q6); F90 semantics live in the oracle"
         ngpt, nlev, ncol = gpt_flux.shape

@@ -312,4 +312,34 @@ void ref_net_broadband_precalc(int ncol, int nlev, const Float* flux_dn, const F
 {
     host_launch(dim3(ncol, nlev), ref_flx::net_broadband_precalc_kernel, ncol, nlev, flux_dn, flux_up, flux_net);
 }
+
+// boundary-condition and transpose launchers on their own (rte_solver_kernels_launchers.cu:20-45,
+// gas_optics_rrtmgp_kernels_launchers.cu:20-58): kernels rte_solver_kernels.cu:351-387, gas_optics_rrtmgp_kernels.cu:76-111
+void ref_apply_BC_0(int ncol, int nlay, int ngpt, Bool top_at_1, Float* gpt_flux_dn)
+{
+    host_launch(dim3(ncol, ngpt), static_cast<void(*)(const int, const int, const int, const Bool, Float*)>(ref_rte::apply_BC_kernel),
+            ncol, nlay, ngpt, top_at_1, gpt_flux_dn);
+}
+
+void ref_apply_BC_gpt(int ncol, int nlay, int ngpt, Bool top_at_1, const Float* inc_flux, Float* gpt_flux_dn)
+{
+    host_launch(dim3(ncol, ngpt), static_cast<void(*)(const int, const int, const int, const Bool, const Float*, Float*)>(ref_rte::apply_BC_kernel),
+            ncol, nlay, ngpt, top_at_1, inc_flux, gpt_flux_dn);
+}
+
+void ref_apply_BC_factor(int ncol, int nlay, int ngpt, Bool top_at_1, const Float* inc_flux, const Float* factor, Float* gpt_flux_dn)
+{
+    host_launch(dim3(ncol, ngpt), static_cast<void(*)(const int, const int, const int, const Bool, const Float*, const Float*, Float*)>(ref_rte::apply_BC_kernel),
+            ncol, nlay, ngpt, top_at_1, inc_flux, factor, gpt_flux_dn);
+}
+
+void ref_reorder123x321(int ni, int nj, int nk, const Float* arr_in, Float* arr_out)
+{
+    host_launch(dim3(ni, nj, nk), ref_gas::reorder123x321_kernel, ni, nj, nk, arr_in, arr_out);
+}
+
+void ref_reorder12x21(int ni, int nj, const Float* arr_in, Float* arr_out)
+{
+    host_launch(dim3(ni, nj), ref_gas::reorder12x21_kernel, ni, nj, arr_in, arr_out);
+}
 }

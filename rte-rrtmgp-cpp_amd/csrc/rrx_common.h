@@ -6,12 +6,24 @@
 #include <cfloat>
 #include <cmath>
 #include <string>
+#include <vector>
+#include <stdexcept>
 
 typedef signed char Bool;   // RTE_USE_CBOOL in every shipped reference config (config/ubuntu_22lts.cmake:35)
 
 namespace rrx
 {
-extern int g_bb_min_groups;     // defined in rrx_solver_sw.hip; set through rrx_set_broadband_min_groups
+    // ---- per-thread settings of the device layer (re-entrant per device / host thread). The rrx_set_*
+    //      entry points change the CALLING thread's copy only; a thread that never calls them runs the defaults.
+    struct Tuning
+    {
+        int lw_variant = 0;        // rrx_set_lw_variant: kernel tiling for A/B runs (0 = default)
+        int sw_variant = 0;        // rrx_set_sw_variant
+        int bb_min_groups = 512;   // rrx_set_broadband_min_groups: column groups needed for the one-pass broadband form
+        int sync_waves = 1;        // partner waves issue their load bursts together (env RRX_SYNC, default on)
+        int go_share = 1;          // Planck shared-cell path (env RRX_GO_SHARE, default on)
+    };
+    Tuning& tuning();              // defined in rrx_misc.hip (thread_local)
 
     // ---- error plumbing: C-ABI functions return int, message retrievable with rrx_last_error() ----
     void set_error(const std::string& msg);
@@ -95,6 +107,28 @@ extern int g_bb_min_groups;     // defined in rrx_solver_sw.hip; set through rrx
     __device__ __forceinline__ float fast_rcp(const float x) { return 1.0f / x; }
 
     inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
+
+    // Stream-ordered scratch that is returned to the pool on every exit path (a throw after the first allocation must
+    // not leak the earlier ones: a transient out-of-memory in a long-running host model would become permanent).
+    class StreamScratch
+    {
+        public:
+            explicit StreamScratch(hipStream_t st) : st_(st) {}
+            StreamScratch(const StreamScratch&) = delete;
+            StreamScratch& operator=(const StreamScratch&) = delete;
+            template<typename F> F* get(const size_t n, const bool zero = false)
+            {
+                void* p = nullptr;
+                if (hipMallocAsync(&p, n*sizeof(F), st_) != hipSuccess) throw std::runtime_error("workspace allocation failed");
+                ptrs_.push_back(p);
+                if (zero && hipMemsetAsync(p, 0, n*sizeof(F), st_) != hipSuccess) throw std::runtime_error("workspace memset failed");
+                return static_cast<F*>(p);
+            }
+            ~StreamScratch() { for (void* p : ptrs_) (void)hipFreeAsync(p, st_); }
+        private:
+            hipStream_t st_;
+            std::vector<void*> ptrs_;
+    };
 }
 
 #define RRX_TRY try {

@@ -868,7 +868,6 @@ __global__ void reorder12x21_kernel(const int ni, const int nj, const F* __restr
 }
 
 // shared-cell path of the gather kernels (RRX_GO_SHARE=0 turns it off for A/B runs)
-int g_go_share = getenv("RRX_GO_SHARE") ? atoi(getenv("RRX_GO_SHARE")) : 1;
 
 inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*8)); }
 
@@ -1033,7 +1032,7 @@ int rrx_compute_planck_source##SFX( \
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
     planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F) + size_t((2*ngpt + 3) & ~3)*sizeof(int) + size_t(PL)*2*4*GCH*2*sizeof(F), static_cast<hipStream_t>(stream)>>>( \
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
-            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac, g_go_share); \
+            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share); \
     RRX_CATCH("rrx_compute_planck_source") \
 } \
 int rrx_reorder123x321##SFX(int ni, int nj, int nk, const F* arr_in, F* arr_out, void* stream) \

@@ -12,6 +12,17 @@ namespace rrx
 {
     static thread_local std::string g_last_error;
     void set_error(const std::string& msg) { g_last_error = msg; }
+    Tuning& tuning()
+    {
+        static thread_local Tuning t = []
+        {
+            Tuning d;
+            if (const char* e = getenv("RRX_SYNC")) d.sync_waves = atoi(e);
+            if (const char* e = getenv("RRX_GO_SHARE")) d.go_share = atoi(e);
+            return d;
+        }();
+        return t;
+    }
     int check_launch(const char* what)
     {
         const hipError_t e = hipGetLastError();

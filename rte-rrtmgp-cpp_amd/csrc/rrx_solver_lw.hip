@@ -24,7 +24,6 @@ using namespace rrx;
 #ifndef RRX_LW_DEFAULT_VARIANT
 #define RRX_LW_DEFAULT_VARIANT 5
 #endif
-int g_lw_sync = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
 constexpr int CL = 8;    // column lanes
 constexpr int LL = 8;    // level lanes
 
@@ -440,7 +439,7 @@ void launch_scan_k(
 {
 #define RRX_LW_ARGS ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, sfc_src_jac, flux_up_jac
-#define RRX_LW_KARGS RRX_LW_ARGS, g_lw_sync
+#define RRX_LW_KARGS RRX_LW_ARGS, tuning().sync_waves
     if (jac)
     {
         if (acc) lw_noscat_scan_kernel<F,V,K,W,true,true><<<grid, 256, 0, st>>>(RRX_LW_KARGS);
@@ -511,7 +510,6 @@ bool launch_scan_bb16(
     return false;
 }
 
-int g_lw_variant = 0;
 
 #define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac
@@ -532,6 +530,8 @@ int lw_solver_noscat_impl(
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     if (nmus < 1 || nmus > 4) throw std::runtime_error("n_quad_angs must be 1..4");
     const bool jac = do_jacobians && sfc_src_jac != nullptr && flux_up_jac != nullptr;
+    const int g_lw_variant = tuning().lw_variant;
+    const int g_bb_min_groups = tuning().bb_min_groups;
 
     // broadband mode, fused form: g-point sums kept in registers, no per-g-point fluxes in memory. Taken when there are
     // enough column groups to fill the chip without splitting the g-point range (which keeps sum_broadband's order).
@@ -561,13 +561,12 @@ int lw_solver_noscat_impl(
 
     // broadband mode, general form: per-g-point fluxes go to a workspace, then are summed over g-points
     F* up = flux_up; F* dn = flux_dn;
-    F* ws = nullptr;
+    StreamScratch scratch(st);
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     if (do_broadband)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
-        if (hipMallocAsync(reinterpret_cast<void**>(&ws), 2*nlevcol*ngpt*sizeof(F), st) != hipSuccess)
-            throw std::runtime_error("workspace allocation failed");
+        F* ws = scratch.get<F>(2*nlevcol*ngpt);
         up = ws; dn = ws + nlevcol*ngpt;
     }
 
@@ -608,7 +607,6 @@ int lw_solver_noscat_impl(
         const int nb = ceil_div(nlevcol, 256);
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, up, flux_up_loc);
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dn, flux_dn_loc);
-        (void)hipFreeAsync(ws, st);
     }
     RRX_CATCH("rrx_lw_solver_noscat")
 }
@@ -617,7 +615,7 @@ int lw_solver_noscat_impl(
 
 extern "C"
 {
-int rrx_set_lw_variant(int v) { g_lw_variant = v; return 0; }
+int rrx_set_lw_variant(int v) { rrx::tuning().lw_variant = v; return 0; }
 
 int rrx_lw_secants_array_f64(int ncol, int ngpt, int n_gauss_quad, int max_gauss_pts, const double* gauss_Ds, double* secants, void* stream)
 {

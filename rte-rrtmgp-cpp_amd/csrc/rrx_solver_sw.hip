@@ -17,13 +17,6 @@
 
 #pragma clang fp contract(fast)
 
-namespace rrx
-{
-// column groups (8*V columns x all levels) needed before the solvers take the fused broadband form: below that the
-// groups alone do not fill the chip and splitting the g-point range would change the summation order
-int g_bb_min_groups = 512;       // measured: fused wins from 4096 fp64 columns (512 groups) up, the workspace form below 2048
-}
-
 namespace
 {
 using namespace rrx;
@@ -567,11 +560,6 @@ __global__ void apply_BC_kernel(const int ncol, const int nlay, const int ngpt, 
     flux_dn[o] = v;
 }
 
-int g_sw_variant = 0;   // 0 = auto (scan), 1 = force serial
-int g_sync_waves = getenv("RRX_SYNC") ? atoi(getenv("RRX_SYNC")) : 1;
-
-extern int g_sync_waves;
-
 template<typename F, int V, int W>
 bool launch_scan(hipStream_t st,
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
@@ -582,7 +570,7 @@ bool launch_scan(hipStream_t st,
     const int need = ceil_div(nlay+1, LL*W);
 #define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK,W><<<grid, 256, 0, st>>>( \
         ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-        flux_up, flux_dn, flux_dir, g_sync_waves); return true; }
+        flux_up, flux_dn, flux_dir, tuning().sync_waves); return true; }
     if constexpr (W == 1) { RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33) }
     else                  { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6)  RRX_SW_K(9)  RRX_SW_K(12) RRX_SW_K(17) }
 #undef RRX_SW_K
@@ -600,10 +588,10 @@ bool launch_scan_bb(hipStream_t st,
 #define RRX_SW_K(KK) if (need <= KK) { \
         if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            flux_up, flux_dn, flux_dir, g_sync_waves); \
+            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
         else sw_2stream_scan_kernel<F,V,KK,2,true,false><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            flux_up, flux_dn, flux_dir, g_sync_waves); \
+            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
         return true; }
     RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12)
 #undef RRX_SW_K
@@ -623,6 +611,8 @@ int sw_solver_2stream_impl(
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const F* dif = has_dif_bc ? inc_flux_dif : nullptr;
+    const int g_sw_variant = tuning().sw_variant;
+    const int g_bb_min_groups = tuning().bb_min_groups;
 
     // broadband mode, fused form (see the kernel's BB note); taken when the column groups alone fill the chip
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
@@ -636,24 +626,16 @@ int sw_solver_2stream_impl(
     }
 
     // g == nullptr (asymmetry identically zero) is native to the fused broadband kernels only: the other forms read zeros
-    F* gzeros = nullptr;
-    if (g == nullptr)
-    {
-        const size_t nb = size_t(ncol)*nlay*ngpt*sizeof(F);
-        if (hipMallocAsync(reinterpret_cast<void**>(&gzeros), nb, st) != hipSuccess || hipMemsetAsync(gzeros, 0, nb, st) != hipSuccess)
-            throw std::runtime_error("workspace allocation failed");
-        g = gzeros;
-    }
+    StreamScratch scratch(st);
+    if (g == nullptr) g = scratch.get<F>(size_t(ncol)*nlay*ngpt, true);
 
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
-    F* ws = nullptr;
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     if (do_broadband)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
             throw std::runtime_error("do_broadband needs flux_*_loc");
-        if (hipMallocAsync(reinterpret_cast<void**>(&ws), 3*nlevcol*ngpt*sizeof(F), st) != hipSuccess)
-            throw std::runtime_error("workspace allocation failed");
+        F* ws = scratch.get<F>(3*nlevcol*ngpt);
         up = ws; dn = ws + nlevcol*ngpt; dr = ws + 2*nlevcol*ngpt;
     }
 
@@ -675,14 +657,11 @@ int sw_solver_2stream_impl(
     }
     if (!done)
     {
-        F* ws2 = nullptr;
         const size_t words = 5*size_t(ncol)*nlay*ngpt + 2*nlevcol*ngpt;
-        if (hipMallocAsync(reinterpret_cast<void**>(&ws2), words*sizeof(F), st) != hipSuccess)
-            throw std::runtime_error("workspace allocation failed");
+        F* ws2 = scratch.get<F>(words);
         const dim3 grid(ceil_div(ncol, 256), ngpt);
         sw_2stream_serial_kernel<F><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0,
                 sfc_alb_dir, sfc_alb_dif, inc_flux_dir, dif, up, dn, dr, ws2);
-        (void)hipFreeAsync(ws2, st);
     }
 
     if (do_broadband)
@@ -691,9 +670,7 @@ int sw_solver_2stream_impl(
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, up, flux_up_loc);
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dn, flux_dn_loc);
         sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, ngpt, dr, flux_dir_loc);
-        (void)hipFreeAsync(ws, st);
     }
-    if (gzeros != nullptr) (void)hipFreeAsync(gzeros, st);
     RRX_CATCH("rrx_sw_solver_2stream")
 }
 
@@ -710,8 +687,8 @@ int apply_BC_impl(int ncol, int nlay, int ngpt, Bool top_at_1, const F* inc, con
 
 extern "C"
 {
-int rrx_set_sw_variant(int v) { g_sw_variant = v; return 0; }
-int rrx_set_broadband_min_groups(int n) { g_bb_min_groups = n; return 0; }
+int rrx_set_sw_variant(int v) { rrx::tuning().sw_variant = v; return 0; }
+int rrx_set_broadband_min_groups(int n) { rrx::tuning().bb_min_groups = n; return 0; }
 
 #define RRX_DEFINE_SW(F, SFX) \
 int rrx_sw_solver_2stream##SFX( \

@@ -213,6 +213,29 @@ class HipKernels:
                 kd.totplnk, kd.gpoint_flavor, out["sfc_src"], out["lay_src"], out["lev_src"], out["sfc_src_jac"])
         return out
 
+    # ---- stand-alone boundary conditions and transposes (launcher parity with the reference's namespaces) ----
+    def apply_BC(self, nlay, top_at_1, flux_dn, inc_flux=None, factor=None):
+        ngpt, nlev, ncol = flux_dn.shape
+        if inc_flux is None:
+            self._c("apply_BC_0", ncol, nlay, ngpt, BoolArg(top_at_1), flux_dn)
+        elif factor is None:
+            self._c("apply_BC_gpt", ncol, nlay, ngpt, BoolArg(top_at_1), inc_flux, flux_dn)
+        else:
+            self._c("apply_BC_factor", ncol, nlay, ngpt, BoolArg(top_at_1), inc_flux, factor, flux_dn)
+        return flux_dn
+
+    def reorder123x321(self, arr_in):
+        ni, nj, nk = arr_in.shape
+        out = self.empty((nk, nj, ni))
+        self._c("reorder123x321", ni, nj, nk, arr_in, out)
+        return out
+
+    def reorder12x21(self, arr_in):
+        ni, nj = arr_in.shape
+        out = self.empty((nj, ni))
+        self._c("reorder12x21", ni, nj, arr_in, out)
+        return out
+
     # ---- optical props / fluxes -----------------------------------------------------------------------
     def increment_1scalar_by_1scalar(self, tau_inout, tau_in):
         ngpt, nlay, ncol = tau_inout.shape

@@ -51,6 +51,9 @@ void Optical_props_2str_gpu::materialize_g() const
 void Optical_props_2str_gpu::delta_scale(const Array_gpu<Float,3>& forward_frac)
 {
     if (forward_frac.size() > 0) throw std::runtime_error("delta_scale with a forward fraction is not on the reference's path");
+    // g == 0 everywhere (lazy form of clear-sky gas optics): f = g*g = 0, so tau, ssa and g are unchanged
+    // (optical_props_kernels.cu:140-161 with g = 0 is the identity); the array behind g is not valid in this state
+    if (g_zero) return;
     Optical_props_kernels_cuda::delta_scale_2str_k(get_ncol(), get_nlay(), get_ngpt(), tau.ptr(), ssa.ptr(), g.ptr());
 }
 

@@ -53,3 +53,41 @@ def gather_fluxes(local, ncol_total, group=None):
         s, e = column_range(r, world, ncol_total)
         parts.append(out[r, :, :, :e - s])
     return torch.cat(parts, dim=-1)
+
+
+class FluxGatherer:
+    """The flux gather of a resident solver: buffers allocated once, ONE all_gather_into_tensor per solve, equal shards
+    gathered in place (no padding copy), ragged ones through a padded staging buffer. `result()` returns the
+    (nflux, nlev, ncol_total) view-or-copy of the last gather. Backend-agnostic: RCCL ("nccl") on GPUs, gloo in the CPU tests."""
+
+    def __init__(self, ncol_total, local_like, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.ncol_total = ncol_total
+        nflux, nlev, nloc = local_like.shape
+        self.shape = (nflux, nlev)
+        self.nmax = -(-ncol_total // self.world)
+        s, e = column_range(self.rank, self.world, ncol_total)
+        assert e - s == nloc, f"rank {self.rank} owns {e - s} columns but its flux buffer holds {nloc}"
+        self.even = (ncol_total % self.world == 0)
+        self.out = torch.empty((self.world*nflux, nlev, self.nmax), dtype=local_like.dtype, device=local_like.device)
+        self.stage = None if self.even else torch.zeros((nflux, nlev, self.nmax), dtype=local_like.dtype, device=local_like.device)
+
+    def gather(self, local):
+        if self.even:
+            src = local if local.is_contiguous() else local.contiguous()
+        else:
+            self.stage[..., :local.shape[-1]] = local
+            src = self.stage
+        dist.all_gather_into_tensor(self.out, src, group=self.group)
+        return self.out
+
+    def result(self):
+        nflux, nlev = self.shape
+        out = self.out.view(self.world, nflux, nlev, self.nmax)
+        parts = []
+        for r in range(self.world):
+            s, e = column_range(r, self.world, self.ncol_total)
+            parts.append(out[r, :, :, :e - s])
+        return torch.cat(parts, dim=-1)

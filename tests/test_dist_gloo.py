@@ -36,6 +36,67 @@ def _worker(rank, world, port, ncol, q):
         dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, scaling, ncol, q):
+    """The sharding + gather code bench.py itself runs for N > 1 (bench.local_atmosphere, sharding.FluxGatherer), with the
+    per-rank solve on the CPU oracle: the gathered fluxes must equal the single-rank solve of the same job bit for bit."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+        import bench, oracle_py
+        from rte_rrtmgp_cpp_amd import synthetic, pipeline, sharding
+        be = oracle_py.CpuKernels("oracle", np.float64)
+        kw = dict(ngpt=32, nbnd=2, npres=10, nflav=3, nminor_lower=5, nminor_upper=3)
+        kl, ks = be.upload_kdist(synthetic.make_kdist("lw", **kw)), be.upload_kdist(synthetic.make_kdist("sw", **kw))
+        args = argparse.Namespace(ncol=ncol, nlay=20, scaling=scaling)
+
+        def solve(atm):
+            lw = pipeline.solve_lw(be, kl, atm, do_broadband=True); sw = pipeline.solve_sw(be, ks, atm, do_broadband=True)
+            return np.stack([lw["flux_up"], lw["flux_dn"], lw["flux_net"], sw["flux_up"], sw["flux_dn"], sw["flux_dn_dir"], sw["flux_net"]])
+
+        ntot = bench.global_columns(args, world)
+        (s, e), mine = bench.local_atmosphere(args, 2, rank, world)
+        assert (s, e) == sharding.column_range(rank, world, ntot) and mine.ncol == e - s
+        local = torch.from_numpy(solve(mine))
+        gat = sharding.FluxGatherer(ntot, local)
+        gat.gather(local)
+        got = gat.result().numpy()
+        if rank == 0:
+            one = argparse.Namespace(ncol=ntot, nlay=20, scaling="strong")
+            (s1, e1), full = bench.local_atmosphere(one, 2, 0, 1)
+            q.put(bool((s1, e1) == (0, ntot) and np.array_equal(got, solve(full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,scaling,ncol", [(2, "weak", 6), (2, "strong", 9), (3, "strong", 10)])
+def test_bench_sharding_path_on_gloo(world, scaling, ncol, oracle_built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + 7*world + len(scaling)
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, scaling, ncol, q)) for r in range(world)]
+    for p in procs: p.start()
+    for p in procs: p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert q.get(timeout=10) is True
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must spawn N ranks itself: checked through --dry-run,
+    which prints the child command instead of running it (no GPU here)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--dry-run"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = out.stdout.strip().split()
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=8" in cmd and "--master-addr" in cmd and "127.0.0.1" in cmd
+    assert cmd[-5:] == ["--gpus", "8", "--steps", "3", "--dry-run"] and any(c.endswith("bench.py") for c in cmd)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert one.returncode == 0 and "torch.distributed.run" not in one.stdout
+
+
 @pytest.mark.parametrize("world,ncol", [(2, 10), (3, 10)])
 def test_column_sharding_and_flux_gather(world, ncol, oracle_built):
     ctx = mp.get_context("spawn")

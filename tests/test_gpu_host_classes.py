@@ -114,3 +114,10 @@ def test_driver_error_behaviour(case):
     assert run_driver(case["dir"], "--bogus-option") == 1
     assert run_driver(case["dir"], "--aerosol-optics") == 1
     assert run_driver(os.path.dirname(case["dir"])) == 1        # no input file there
+
+
+def test_delta_scale_on_lazy_zero_g_is_the_identity():
+    """ADVICE r01: Optical_props_2str_gpu::delta_scale() on gas-only optical properties in the lazy g == 0 state must not
+    hand the stale g array to the kernel (C++ self-check exported by the host library)."""
+    lib = ctypes.CDLL(HOSTLIB)
+    assert lib.rrx_host_selftest_delta_scale_gzero() == 0

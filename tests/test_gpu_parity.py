@@ -35,6 +35,16 @@ def test_hip_random_solvers_match_reference_golden(path, hip_f64, hip_f32):
     print(sorted(worst.items(), key=lambda kv: -kv[1])[:4])
 
 
+@pytest.mark.parametrize("path", cases.golden_files("glue_"), ids=os.path.basename)
+def test_hip_standalone_bc_and_transposes_match_reference_golden(path, hip_f64, hip_f32):
+    """rrx_apply_BC_{0,gpt,factor}, rrx_reorder123x321 / 12x21 bit for bit against the reference kernels
+    (rte_solver_kernels.cu:351-387, gas_optics_rrtmgp_kernels.cu:76-111), and the LW incident-flux convention (Q3)."""
+    G = np.load(path)
+    be = hip_f64 if cases.dtype_of(G) == np.float64 else hip_f32
+    worst = cases.run_glue_case(be, G, tol=TOL64 if be is hip_f64 else TOL32)
+    print("worst rel err:", sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+
+
 def _solve_both(hip, orc, kind, ncol, nlay, top_at_1, clouds, ngpt=64, nbnd=4, **kw):
     kd0 = synthetic.make_kdist(kind, ngpt=ngpt, nbnd=nbnd, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
     atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, top_at_1=top_at_1, clouds=clouds, seed=3)
@@ -363,3 +373,87 @@ def test_full_size_default_flow_matches_per_gpoint_flow(dt, hip_f64, hip_f32):
         tol = 1e-12 if dt == "f64" else (1e-3 if name.startswith("sw") else 2e-5)
         assert cases.rel_err(a[i], b[i], floor=1e-6 if dt == "f64" else 1e-2) <= tol, name
 
+
+
+# ---- BASELINE's own spectral shapes: full flavor / minor-interval structure, 140 layers ----------------
+REAL_SHAPES = {"lw": dict(ngpt=256, nbnd=16), "sw": dict(ngpt=224, nbnd=14)}     # rrtmgp-gas-lw-g256 / rrtmgp-gas-sw-g224
+
+
+def _worst(h, o, keys, floor=1e-6):
+    return {k: cases.rel_err(h[k], o[k], floor) for k in keys}
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_real_spectral_shape_matches_oracle(kind, top_at_1, hip_f64, oracle_f64):
+    """LW 256 g-points / 16 bands, SW 224 / 14, 10 flavors, 44 + 19 minor intervals (704 / 304 contributors), 59 pressures,
+    132 columns x 140 layers: optical depths, single-scattering albedo, sources and broadband fluxes of the HIP path (default
+    product flow: store-form tau, fused SW gas optics, no g array) against the CPU oracle, both vertical orientations."""
+    kd0 = synthetic.make_kdist(kind, **REAL_SHAPES[kind])
+    assert kd0.nflav == 10 and kd0.minor_limits_gpt_lower.shape[0] == 44 and kd0.minor_limits_gpt_upper.shape[0] == 19
+    nb = REAL_SHAPES[kind]["nbnd"]
+    atm0 = synthetic.make_atmosphere(132, 140, nbnd_lw=nb, nbnd_sw=nb, top_at_1=top_at_1, seed=41)
+    res = []
+    for be in (hip_f64, oracle_f64):
+        kd = be.upload_kdist(kd0)
+        atm = pipeline.upload_atmosphere(be, atm0)
+        r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, keep=True)
+        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
+    h, o = res
+    keys = ("tau", "flux_up", "flux_dn", "flux_net", "gpt_flux_up", "gpt_flux_dn") + \
+           (("lay_src", "lev_src", "sfc_src") if kind == "lw" else ("ssa", "toa_src", "flux_dn_dir", "gpt_flux_dir"))
+    worst = _worst(h, o, keys)
+    print(f"real-shape {kind} top_at_1={top_at_1}: worst rel err", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    for k, e in worst.items():
+        assert e <= (1e-7 if (kind == "sw" and "flux" in k) else 1e-9), f"{kind} {k}: {e:.3e}"
+    # and the broadband-solver flow the headline uses, on the same inputs
+    hip_f64.set_broadband_min_groups(1)
+    try:
+        kd = hip_f64.upload_kdist(kd0); atm = pipeline.upload_atmosphere(hip_f64, atm0)
+        rb = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(hip_f64, kd, atm, do_broadband=True)
+    finally:
+        hip_f64.set_broadband_min_groups(512)
+    for k in ("flux_up", "flux_dn", "flux_net"):
+        e = cases.rel_err(hip_f64.to_numpy(rb[k]), o[k])
+        assert e <= (1e-7 if kind == "sw" else 1e-9), f"broadband flow {kind} {k}: {e:.3e}"
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32):
+    """BASELINE C5: all-sky LW+SW in single precision at the real column shape (140 layers x 256 g-points; 192 columns, two
+    of every three cloudy): cloud optics (1scl / 2str), delta scaling, the by-band increments and the full solve against the
+    fp32 oracle. Tolerances: fp32 round-off through 140-layer recurrences (2e-4); SW fluxes 1e-3 (k_min / resonance clamps
+    in single precision, as in the fp32 random golden case)."""
+    be_h, be_o = hip_f32, oracle_f32
+    ngpt, nbnd, ncol, nlay = 256, 16, 192, 140
+    kd0 = synthetic.make_kdist(kind, ngpt=ngpt, nbnd=nbnd)
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, clouds=True, seed=55).astype(np.float32)
+    lut0 = synthetic.make_cloud_lut(nbnd, kind)
+    assert (atm0.lwp > 0).any() and (atm0.lwp[:, 2::3] == 0).all(), "every third column is clear (allsky_init.py:167-176)"
+    # (a) the cloud kernels on their own
+    outs = []
+    for be in (be_h, be_o):
+        l = be.upload_lut(lut0); up = be.asarray
+        if kind == "lw":
+            c = [be.cloud_optics_1scl(l, up(atm0.lwp), up(atm0.iwp), up(atm0.rel), up(atm0.dei))]
+        else:
+            t, w, g = be.cloud_optics_2str(l, up(atm0.lwp), up(atm0.iwp), up(atm0.rel), up(atm0.dei))
+            be.delta_scale_2str_k(t, w, g)
+            c = [t, w, g]
+        outs.append([be.to_numpy(x) for x in c])
+    for i, (a_, b_) in enumerate(zip(*outs)):
+        e = cases.rel_err(a_, b_, floor=1e-2)
+        assert e <= 2e-5, f"cloud optics {kind} output {i}: {e:.3e}"
+    # (b) gas optics + clouds + increments + solver + reduction
+    res = []
+    for be in (be_h, be_o):
+        kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0); lut = be.upload_lut(lut0)
+        kw = dict(delta_cloud=True) if kind == "sw" else {}
+        r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, cloud_lut=lut, keep=True, **kw)
+        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
+    h, o = res
+    keys = ("tau", "flux_up", "flux_dn", "flux_net") + (("ssa", "g", "flux_dn_dir") if kind == "sw" else ("lay_src", "lev_src"))
+    worst = _worst(h, o, keys, floor=1e-2)
+    print(f"C5 fp32 all-sky {kind}: worst rel err", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    for k, e in worst.items():
+        assert e <= (1e-3 if (kind == "sw" and "flux" in k) else 2e-4), f"{kind} {k}: {e:.3e}"

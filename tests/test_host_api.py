@@ -51,6 +51,7 @@ def test_host_library_exports_driver_entry():
     lib = os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "librte_rrtmgp_hip.so")
     assert os.path.exists(lib), "run __graft_entry__.build()"
     assert hasattr(ctypes.CDLL(lib), "rrx_host_main")
+    assert hasattr(ctypes.CDLL(lib), "rrx_host_selftest_delta_scale_gzero")
     assert os.path.exists(os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "test_rte_rrtmgp_gpu"))
 
 
