@@ -45,20 +45,37 @@ struct TwoStream { F r_dif, t_dif, r_dir, t_dir, t_noscat; };
 // /root/reference/src_kernels_cuda/rte_solver_kernels.cu:543-592 (Zdunkowski PIFM two-stream, Ukkonen clamps).
 // Same formulas; the three divisions per cell (1/mu0, rt_term, /fact) are replaced by one hoisted reciprocal of mu0
 // and ONE Newton reciprocal x = 1/(D*fact): rt_term = x*fact, rt_term2 = ssa*x (fp64 vector rate is the scarce
-// resource of this kernel: DESIGN.md section "sw_solver_2stream").
-template<typename F>
+// resource of this kernel: DESIGN.md section "sw_solver_2stream"). fp64: exp and sqrt are the lean forms of
+// rrx_common.h (arguments are <= 0 resp. in [1e-12, 16]). GZ: asymmetry identically zero (clear-sky gas optics), the
+// same expressions with g = 0 folded in by hand: gamma3 = gamma4 = 1/2, alpha1 = alpha2 = (gamma1 + gamma2)/2.
+template<typename F, bool GZ = false>
 __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, const F g, const F mu0, const F mu0_inv)
 {
     TwoStream<F> o;
     const F tmin = Lim<F>::eps();
-    const F gamma1 = (F(8.) - ssa * (F(5.) + F(3.) * g)) * F(.25);
-    const F gamma2 = F(3.) * (ssa * (F(1.) - g)) * F(.25);
-    const F gamma3 = (F(2.) - F(3.) * mu0 * g) * F(.25);
-    const F gamma4 = F(1.) - gamma3;
-    const F alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
-    const F alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-    const F k = sqrt(max((gamma1 - gamma2) * (gamma1 + gamma2), Lim<F>::k_min()));
-    const F exp_minusktau = exp(-tau * k);
+    F gamma1, gamma2, alpha1, alpha2, k_gamma3, k_gamma4, k;
+    if constexpr (GZ)
+    {
+        gamma1 = fma(F(-1.25), ssa, F(2.));
+        gamma2 = F(.75) * ssa;
+        const F sum = gamma1 + gamma2;
+        k = sqrt_pos(max((gamma1 - gamma2) * sum, Lim<F>::k_min()));
+        alpha1 = alpha2 = F(.5) * sum;
+        k_gamma3 = k_gamma4 = F(.5) * k;
+    }
+    else
+    {
+        gamma1 = (F(8.) - ssa * (F(5.) + F(3.) * g)) * F(.25);
+        gamma2 = F(3.) * (ssa * (F(1.) - g)) * F(.25);
+        const F gamma3 = (F(2.) - F(3.) * mu0 * g) * F(.25);
+        const F gamma4 = F(1.) - gamma3;
+        alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+        alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+        k = sqrt_pos(max((gamma1 - gamma2) * (gamma1 + gamma2), Lim<F>::k_min()));
+        k_gamma3 = k * gamma3;
+        k_gamma4 = k * gamma4;
+    }
+    const F exp_minusktau = exp_neg(-tau * k);
     const F exp_minus2ktau = exp_minusktau * exp_minusktau;
     const F k_mu = k * mu0;
     const F omk2 = F(1.) - k_mu*k_mu;
@@ -78,9 +95,7 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
     }
     o.r_dif = rt_term * gamma2 * (F(1.) - exp_minus2ktau);
     o.t_dif = rt_term * F(2.) * k * exp_minusktau;
-    o.t_noscat = exp(-tau * mu0_inv);
-    const F k_gamma3 = k * gamma3;
-    const F k_gamma4 = k * gamma4;
+    o.t_noscat = exp_neg(-tau * mu0_inv);
     const F r_dir = rt_term2 * ((F(1.) - k_mu) * (alpha2 + k_gamma3) -
                                 (F(1.) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
                                 F(2.) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * o.t_noscat);
@@ -99,7 +114,11 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // BB (broadband): the workgroup walks over ALL g-points of its columns and keeps the g-point sums of the three fluxes
 // on chip (up and dn in LDS, dir in registers), added in g-point order like sum_broadband does on stored per-g-point
 // fluxes, so the same bits; flux_up/dn/dir are then (ncol, nlev) arrays.
-template<typename F, int V, int K, int W, bool BB = false, bool GZ = false>
+// PRE (BB form without g array): software pipeline over the g-point loop. The K layers of tau and ssa of g-point g+1 are
+// requested right after the two-stream phase of g-point g, when the registers of its temporaries are free, and land
+// during the scans and replays; the next iteration finds them in registers. Measured at C4 (tools/sw_lab.hip): 5.3 -> 4.7 ms;
+// loads issued layer by layer inside the two-stream phase were still in flight when their layer came up.
+template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false>
 __global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
@@ -151,10 +170,27 @@ sw_2stream_scan_kernel(
 
     const int g_begin = BB ? 0 : blockIdx.y;
     const int g_end = BB ? ngpt : blockIdx.y + 1;
+
+    // PRE: element offset of layer j inside one g-point slab, recomputed where needed (9 registers less than keeping them)
+    auto off_of = [&](const int j) -> unsigned
+    {
+        const int ml = top_at_1 ? min(t0 + j, nlay-1) : max(nlay-1-t0-j, 0);
+        return unsigned(ml)*unsigned(ncol) + unsigned(icol);
+    };
+    Vec<F,V> nt[PRE ? K : 1], nw[PRE ? K : 1], n_inc, n_adir, n_adif;
+    if constexpr (PRE)
+    {
+        static_assert(BB && GZ && W == 2, "the pipelined form is the fused broadband kernel without g array");
+        #pragma unroll
+        for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau + o); nw[j] = load_cols<F,V>(ssa + o); }
+        n_inc = load_cols<F,V>(inc_flux_dir + icol); n_adir = load_cols<F,V>(sfc_alb_dir + icol); n_adif = load_cols<F,V>(sfc_alb_dif + icol);
+    }
+
     for (int igpt=g_begin; igpt<g_end; ++igpt)
     {
-    // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip)
-    if (sync_waves) __syncthreads();
+    // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip); the pipelined form
+    // issues them behind the first scan barrier instead
+    if constexpr (!PRE) { if (sync_waves) __syncthreads(); }
     const size_t lay_base = size_t(igpt)*ncl*nlay + icol;
     const size_t lev_base = size_t(igpt)*ncl*nlev + icol;
     const size_t sfc_idx = size_t(igpt)*ncl + icol;
@@ -177,6 +213,15 @@ sw_2stream_scan_kernel(
         const int sc = min(s, nlay-1);
         const int ml = top_at_1 ? sc : nlay-1-sc;
         size_t off = lay_base + size_t(ml)*ncl;
+        Vec<F,V> tv, wv, gv;
+        if constexpr (PRE)
+        {
+            tv = nt[j]; wv = nw[j];
+            #pragma unroll
+            for (int v=0; v<V; ++v) gv.v[v] = F(0.);
+        }
+        else
+        {
         // Fused broadband form only (register budget: the g-point sums live across the whole body): empty asm statements
         // tie this layer's loads to the result of layer j-BB_LOADS and each evaluation to the result BB_EVALS evaluations back,
         // so that at most that many layers of loads / two_stream temporaries are live at once. The per-g-point form
@@ -185,15 +230,15 @@ sw_2stream_scan_kernel(
         {
             if (j >= BB_LOADS) asm volatile("" : "+v"(off) : "v"(qb[j-BB_LOADS][V-1]));
         }
-        Vec<F,V> tv = load_cols<F,V>(tau + off);
-        const Vec<F,V> wv = load_cols<F,V>(ssa + off);
-        Vec<F,V> gv;
+        tv = load_cols<F,V>(tau + off);
+        wv = load_cols<F,V>(ssa + off);
         if constexpr (GZ)                                  // asymmetry identically zero (clear-sky gas optics): g is not read
         {
             #pragma unroll
             for (int v=0; v<V; ++v) gv.v[v] = F(0.);
         }
         else gv = load_cols<F,V>(g + off);
+        }
         // (V == 1: the tie sits ahead of the evaluation loop, V > 1: on each column's tau. Same dependence, but the
         //  register allocator lands differently: measured fp64 6.3 vs 8.3 ms and fp32 6.4 vs 4.4 ms, tools/ab_sw.sh)
         if constexpr (BB && V == 1)
@@ -208,7 +253,7 @@ sw_2stream_scan_kernel(
                 const int e = j*V + v - BB_EVALS;             // the evaluation this one waits for
                 if (e >= 0) asm volatile("" : "+v"(tv.v[v]) : "v"(qb[e / V][e % V]));
             }
-            const TwoStream<F> ts = two_stream<F>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
+            const TwoStream<F> ts = two_stream<F,GZ>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
             rp[j][v] = valid ? ts.r_dif : F(0.);
             al[j][v] = valid ? ts.t_dif : F(1.);
             sb[j][v] = valid ? ts.r_dir : F(0.);
@@ -236,11 +281,19 @@ sw_2stream_scan_kernel(
         Tloc[v] = T;
     }
 
-    const Vec<F,V> inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx);
-    const Vec<F,V> a_dir = load_cols<F,V>(sfc_alb_dir + sfc_idx);
-    const Vec<F,V> a_dif = load_cols<F,V>(sfc_alb_dif + sfc_idx);
-    Vec<F,V> inc_dif;
-    if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx);
+    Vec<F,V> inc_dir, a_dir, a_dif, inc_dif;
+    if constexpr (PRE)
+    {
+        inc_dir = n_inc; a_dir = n_adir; a_dif = n_adif;
+        if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx);     // rare: not worth registers across the loop
+    }
+    else
+    {
+        inc_dir = load_cols<F,V>(inc_flux_dir + sfc_idx);
+        a_dir = load_cols<F,V>(sfc_alb_dir + sfc_idx);
+        a_dif = load_cols<F,V>(sfc_alb_dif + sfc_idx);
+        if (inc_flux_dif != nullptr) inc_dif = load_cols<F,V>(inc_flux_dif + sfc_idx);
+    }
 
     F dn_in[V], dir_in[V];
 
@@ -262,6 +315,22 @@ sw_2stream_scan_kernel(
         {
             if (ll == LL-1) xch[8*v+0][wave][cl] = pr;
             __syncthreads();
+            if constexpr (PRE)
+            {
+                if (v == 0)
+                {
+                    // every wave of the workgroup is here: the two waves that share each 128-B line ask for it together
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gn = min(igpt + 1, ngpt - 1);           // (last iteration: a harmless re-read)
+                    const F* __restrict__ tau_n = tau + size_t(gn)*ncl*nlay;
+                    const F* __restrict__ ssa_n = ssa + size_t(gn)*ncl*nlay;
+                    #pragma unroll
+                    for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau_n + o); nw[j] = load_cols<F,V>(ssa_n + o); }
+                    const size_t sn = size_t(gn)*ncl + icol;
+                    n_inc = load_cols<F,V>(inc_flux_dir + sn); n_adir = load_cols<F,V>(sfc_alb_dir + sn); n_adif = load_cols<F,V>(sfc_alb_dif + sn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             const F other = xch[8*v+0][wave^1][cl];
             if (h == 1) pe *= other;
             ptot *= other;
@@ -585,8 +654,12 @@ bool launch_scan_bb(hipStream_t st,
 {
     const dim3 grid(ceil_div(ncol, 2*CL*V), 1);
     const int need = ceil_div(nlay+1, LL*2);
+    const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
 #define RRX_SW_K(KK) if (need <= KK) { \
-        if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
+        if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
+        else if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             flux_up, flux_dn, flux_dir, tuning().sync_waves); \
         else sw_2stream_scan_kernel<F,V,KK,2,true,false><<<grid, 256, 0, st>>>( \
@@ -616,6 +689,7 @@ int sw_solver_2stream_impl(
 
     // broadband mode, fused form (see the kernel's BB note); taken when the column groups alone fill the chip
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+    // (variant 8: fused broadband form without the pipelined loads, for A/B runs)
     if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && ncol % VBB == 0 && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)

@@ -185,8 +185,9 @@ def test_columns_in_different_regimes_within_one_wavefront(kind, hip_f64, oracle
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
-    """g = NULL (asymmetry identically zero: clear-sky gas optics) gives the same bits as an array of zeros, in the
-    per-g-point form (zeros workspace), the workspace broadband form and the fused broadband form (native)."""
+    """g = NULL (asymmetry identically zero: clear-sky gas optics) against an array of zeros: the same bits in the
+    per-g-point form and the workspace broadband form (both read a zero workspace); the fused broadband form has the
+    g == 0 algebra folded into the two-stream coefficients by hand (gamma3 = gamma4 = 1/2, ...), which re-rounds: 1e-12."""
     be = hip_f64 if dt == "f64" else hip_f32
     rng = np.random.default_rng(21)
     ngpt, nlay, ncol = 12, 140, 40
@@ -202,7 +203,11 @@ def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
         finally:
             be.set_broadband_min_groups(512)
         for k in ("flux_up", "flux_dn", "flux_dir"):
-            assert np.array_equal(be.to_numpy(a[k]), be.to_numpy(b[k])), (k, bb, mg)
+            if bb and mg == 1:
+                e = cases.rel_err(be.to_numpy(b[k]), be.to_numpy(a[k]), floor=1e-6 if dt == "f64" else 1e-2)
+                assert e <= (1e-12 if dt == "f64" else 1e-5), (k, e)
+            else:
+                assert np.array_equal(be.to_numpy(a[k]), be.to_numpy(b[k])), (k, bb, mg)
 
 
 @pytest.mark.parametrize("ncol,nlay,ngpt", [(1, 1, 1), (3, 2, 5), (65, 143, 4), (64, 144, 3), (33, 271, 3), (33, 272, 3), (10, 300, 2)])
@@ -370,7 +375,9 @@ def test_full_size_default_flow_matches_per_gpoint_flow(dt, hip_f64, hip_f32):
     for i, name in enumerate(("lw_up", "lw_dn", "lw_net", "sw_up", "sw_dn", "sw_dir", "sw_net")):
         # fp32 SW: the two flows run differently tiled two-stream kernels; single precision near the k_min / resonance
         # clamps moves a flux by a few 1e-4 (same bound as the fp32 random golden case)
-        tol = 1e-12 if dt == "f64" else (1e-3 if name.startswith("sw") else 2e-5)
+        # fp64 SW: the default flow folds g == 0 into the two-stream algebra and uses the lean exp / sqrt, the per-g-point
+        # flow evaluates the general expressions on a zero g array: same mathematics, different rounding (observed 4e-12)
+        tol = (1e-10 if name.startswith("sw") else 1e-12) if dt == "f64" else (2e-3 if name.startswith("sw") else 2e-5)
         assert cases.rel_err(a[i], b[i], floor=1e-6 if dt == "f64" else 1e-2) <= tol, name
 
 
