@@ -159,6 +159,48 @@ int rrx_gas_optics_sw_fused##SFX( \
         const F* play, const F* tlay, const F* col_gas, const F* col_dry, \
         const int* jeta, const int* jtemp, const int* jpress, const F* krayl, \
         F* tau, F* ssa, F* g, void* stream); \
+/* "direct" gas optics: the interpolation state (interpolation_kernel, gas_optics_rrtmgp_kernels.cu:317-395) is computed \
+   inside the consumer from (play, tlay, col_gas) instead of being written by rrx_interpolation and read back by \
+   rrx_compute_tau_absorption / rrx_compute_planck_source: same expressions in the same order, so the same bits, without \
+   the seven intermediate arrays (jtemp, jpress, tropo, jeta, col_mix, fminor, fmajor). What Gas_optics_rrtmgp_gpu::gas_optics \
+   (src_cuda/Gas_optics_rrtmgp.cu:907-1201) runs here. flavor(2,nflav), vmr_ref(2,0:ngas,ntemp) as for rrx_interpolation. */ \
+int rrx_gas_optics_lw_direct##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, F* tau, void* stream); \
+int rrx_gas_optics_sw_direct##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry, const F* krayl, \
+        F* tau, F* ssa, F* g, void* stream); \
+int rrx_planck_source_direct##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
+        F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
+        F* sfc_src, F* lay_src, F* lev_src, F* sfc_src_jac, void* stream); \
 /* ---- Optical_props_kernels_cuda : include_kernels_cuda/optical_props_kernels_cuda.h:33-56 ---- */ \
 int rrx_increment_1scalar_by_1scalar##SFX(int ncol, int nlay, int ngpt, F* tau_inout, const F* tau_in, void* stream); \
 int rrx_increment_2stream_by_2stream##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* ssa_inout, F* g_inout, const F* tau_in, const F* ssa_in, const F* g_in, void* stream); \

@@ -92,6 +92,60 @@ interpolation_kernel(
 }
 
 
+// The interpolation state of ONE cell, recomputed inside the consumers ("direct" entry points) instead of being written by
+// interpolation_kernel and read back: per cell 3 words in (p, T, two column amounts per flavor) against 16 words per flavor
+// out and in again (at C4: 3.5 GB written + 4.5 GB read per chain, and two launches of 0.78 ms). Same expressions, same
+// order as interpolation_kernel above (/root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:317-395), so the
+// two paths agree bit for bit (tests/test_gpu_parity.py::test_direct_gas_optics_equals_interpolation_path).
+template<typename F>
+struct InterpArgs
+{
+    int ngas; const int* flavor; const F* press_ref_log; const F* temp_ref;
+    F press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log; const F* vmr_ref;
+};
+
+template<typename F>
+struct CellState { int jt, jp_raw, itropo; F ftemp, fpress; };
+
+template<typename F>
+__device__ __forceinline__ CellState<F> cell_state(const InterpArgs<F>& ia, const int npres, const int ntemp, const F p, const F t)
+{
+    CellState<F> c;
+    int jt = int((t - (ia.temp_ref_min - ia.temp_ref_delta)) / ia.temp_ref_delta);
+    jt = min(ntemp-1, max(1, jt));
+    c.jt = jt;
+    c.ftemp = (t - ia.temp_ref[jt-1]) / ia.temp_ref_delta;
+    const F lp = log(p);
+    const F locpress = F(1.) + (lp - ia.press_ref_log[0]) / ia.press_ref_log_delta;
+    c.jp_raw = min(npres-1, max(1, int(locpress)));
+    c.fpress = locpress - F(c.jp_raw);
+    c.itropo = (lp > ia.press_ref_trop_log) ? 0 : 1;
+    return c;
+}
+
+// flavor-dependent part for temperature node itemp (0: jt-1, 1: jt): col_mix, jeta, fminor[2], fmajor[4]
+template<typename F>
+__device__ __forceinline__ void flavor_state(const InterpArgs<F>& ia, const CellState<F>& c, const int neta, const int itemp,
+        const int gas1, const int gas2, const F cg1, const F cg2, F& cmix, int& je, F (&fmi)[2], F (&fma)[4])
+{
+    const size_t vbase = c.itropo + size_t(c.jt+itemp-1) * (ia.ngas+1) * 2;
+    const F ratio_eta_half = ia.vmr_ref[vbase + 2*gas1] / ia.vmr_ref[vbase + 2*gas2];
+    cmix = cg1 + ratio_eta_half * cg2;
+    const F eta = (cmix > F(2.)*Lim<F>::tiny()) ? cg1 / cmix : F(0.5);
+    const F loceta = eta * F(neta-1);
+    je = min(int(loceta)+1, neta-1);
+    const F feta = fmod(loceta, F(1.));
+    const F ftemp_term = F(1-itemp) + F(2*itemp-1)*c.ftemp;
+    const F f0 = (F(1.)-feta) * ftemp_term;
+    const F f1 = feta * ftemp_term;
+    fmi[0] = f0; fmi[1] = f1;
+    fma[0] = (F(1.)-c.fpress) * f0;
+    fma[1] = (F(1.)-c.fpress) * f1;
+    fma[2] = c.fpress * f0;
+    fma[3] = c.fpress * f1;
+}
+
+
 // Per-workgroup tables in LDS, built once per workgroup:
 //   gflav[r][ig]           flavor (0-based) of g-point ig in regime r (0 = lower, 1 = upper atmosphere)
 //   lists[r][c] = { count, then per item {imnr, gpt_start, gpt_end, kminor_start-1-gpt_start, flavor} } : the minor
@@ -178,7 +232,9 @@ __device__ __forceinline__ Pair<F> ld2(const F* __restrict__ base, const unsigne
 // major : /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:398-443
 // minor : :458-578      rayleigh : :674-718      combine : :721-746 with the CPU threshold (src/Gas_optics_rrtmgp.cpp:378)
 // A minor interval uses the flavor of its first g-point, exactly as the reference kernel (:533).
-template<typename F, int MODE>
+// DIRECT: the interpolation state is computed in the kernel from (play, tlay, col_gas) -- InterpArgs -- and the arrays
+// tropo / col_mix / fmajor / fminor / jeta / jtemp / jpress are not touched (may be null).
+template<typename F, int MODE, bool DIRECT = false>
 __global__ void __launch_bounds__(256, 2)
 tau_absorption_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
@@ -195,7 +251,7 @@ tau_absorption_kernel(
         const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
         const int* __restrict__ jeta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
         const F* __restrict__ krayl,
-        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const InterpArgs<F> ia)
 {
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
@@ -237,15 +293,18 @@ tau_absorption_kernel(
 
     const size_t ncl = size_t(ncol)*nlay;
     const size_t idx = icol + size_t(ilay)*ncol;
-    const int itropo = tropo[idx] ? 0 : 1;
-    const int jt = jtemp[idx];
-    const int jp = jpress[idx] + itropo;
+    const F pl = play[idx], tl = tlay[idx];
+    CellState<F> cs;
+    if constexpr (DIRECT) cs = cell_state<F>(ia, npres, ntemp, pl, tl);
+    else { cs.itropo = tropo[idx] ? 0 : 1; cs.jt = jtemp[idx]; cs.jp_raw = jpress[idx]; cs.ftemp = F(0.); cs.fpress = F(0.); }
+    const int itropo = cs.itropo;
+    const int jt = cs.jt;
+    const int jp = cs.jp_raw + itropo;
     const int s_eta = ntemp, s_prs = ntemp*neta;
     const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
     const int tn = ntemp*neta;
     constexpr unsigned SZ = sizeof(F);
 
-    const F pl = play[idx], tl = tlay[idx];
     const F cdry0 = col_gas[idx];                         // col_gas(:,:,0) = col_dry
     const F ch2o = col_gas[idx + size_t(idx_h2o)*ncl];
     F ray_fac = F(0.);
@@ -289,15 +348,42 @@ tau_absorption_kernel(
     unsigned q0a=0, q0b=0, q1a=0, q1b=0;       // kminor / krayl
     const unsigned beta = unsigned(s_eta)*SZ;
 
+    // interpolation state of a flavor: from the arrays, or (DIRECT) computed here
+    auto flavor_of_cell = [&](const int iflav, F (&cm)[2], int (&je)[2], F (&fn)[4], F (&fm)[8])
+    {
+        if constexpr (DIRECT)
+        {
+            const int gas1 = rfl(ia.flavor[2*iflav]), gas2 = rfl(ia.flavor[2*iflav+1]);      // iflav is wave-uniform
+            const F cg1 = col_gas[idx + size_t(gas1)*ncl], cg2 = col_gas[idx + size_t(gas2)*ncl];
+            #pragma unroll
+            for (int itemp=0; itemp<2; ++itemp)
+            {
+                F fmi[2], fma[4];
+                flavor_state<F>(ia, cs, neta, itemp, gas1, gas2, cg1, cg2, cm[itemp], je[itemp], fmi, fma);
+                fn[2*itemp] = fmi[0]; fn[2*itemp+1] = fmi[1];
+                fm[4*itemp] = fma[0]; fm[4*itemp+1] = fma[1]; fm[4*itemp+2] = fma[2]; fm[4*itemp+3] = fma[3];
+            }
+        }
+        else
+        {
+            const size_t cell = idx + size_t(iflav)*ncl;
+            #pragma unroll
+            for (int i=0; i<8; ++i) fm[i] = fmajor[8*cell + i];
+            cm[0] = col_mix[2*cell]; cm[1] = col_mix[2*cell+1];
+            je[0] = jeta[2*cell]; je[1] = jeta[2*cell+1];
+            #pragma unroll
+            for (int i=0; i<4; ++i) fn[i] = fminor[4*cell + i];
+        }
+    };
+
     auto load_flavor = [&](const int iflav)
     {
         cur_flav = iflav;
-        const size_t cell = idx + size_t(iflav)*ncl;
-        const F* f = fmajor + 8*cell;
-        fm0=f[0]; fm1=f[1]; fm2=f[2]; fm3=f[3]; fm4=f[4]; fm5=f[5]; fm6=f[6]; fm7=f[7];
-        cm0 = col_mix[2*cell]; cm1 = col_mix[2*cell+1];
-        const int je0 = jeta[2*cell], je1 = jeta[2*cell+1];
-        const F* fn = fminor + 4*cell;
+        F cm[2], fn[4], fm[8]; int je[2];
+        flavor_of_cell(iflav, cm, je, fn, fm);
+        fm0=fm[0]; fm1=fm[1]; fm2=fm[2]; fm3=fm[3]; fm4=fm[4]; fm5=fm[5]; fm6=fm[6]; fm7=fm[7];
+        cm0 = cm[0]; cm1 = cm[1];
+        const int je0 = je[0], je1 = je[1];
         fn0=fn[0]; fn1=fn[1]; fn2=fn[2]; fn3=fn[3];
         same_eta = (je0 == je1);
         b00 = unsigned((jt-1) + (je0-1)*s_eta + (jp-1)*s_prs)*SZ;  b01 = b00 + unsigned(s_prs)*SZ;
@@ -309,9 +395,9 @@ tau_absorption_kernel(
     // minor absorption of a contributor whose flavor is not the band's (does not occur in rrtmgp-data; kept exact)
     auto minor_other_flavor = [&](const int mflav, const F* km) -> F
     {
-        const size_t cell = idx + size_t(mflav)*ncl;
-        const int j0 = jeta[2*cell], j1 = jeta[2*cell+1];
-        const F* fn = fminor + 4*cell;
+        F cm[2], fn[4], fm[8]; int je[2];
+        flavor_of_cell(mflav, cm, je, fn, fm);
+        const int j0 = je[0], j1 = je[1];
         return fn[0]*km[(jt-1) + (j0-1)*ntemp] + fn[1]*km[(jt-1) + j0*ntemp]
              + fn[2]*km[ jt    + (j1-1)*ntemp] + fn[3]*km[ jt    + j1*ntemp];
     };
@@ -613,11 +699,26 @@ template<typename F>
 struct CellInterp
 {
     F fm[8]; int je[2]; int jt, jp;
+    CellState<F> cs;                 // DIRECT form only
     __device__ __forceinline__ void load(const size_t cell, const F* __restrict__ fmajor, const int* __restrict__ jeta)
     {
         #pragma unroll
         for (int i=0; i<8; ++i) fm[i] = fmajor[8*cell + i];
         je[0] = jeta[2*cell]; je[1] = jeta[2*cell+1];
+    }
+    // the same state computed from the column amounts of the flavor's two gases (see flavor_state)
+    __device__ __forceinline__ void load_direct(const InterpArgs<F>& ia, const int neta, const int iflav,
+                                                const F* __restrict__ col_gas, const size_t idx, const size_t ncl)
+    {
+        const int gas1 = ia.flavor[2*iflav], gas2 = ia.flavor[2*iflav+1];
+        const F cg1 = col_gas[idx + size_t(gas1)*ncl], cg2 = col_gas[idx + size_t(gas2)*ncl];
+        #pragma unroll
+        for (int itemp=0; itemp<2; ++itemp)
+        {
+            F cmix, fmi[2], fma[4];
+            flavor_state<F>(ia, cs, neta, itemp, gas1, gas2, cg1, cg2, cmix, je[itemp], fmi, fma);
+            fm[4*itemp] = fma[0]; fm[4*itemp+1] = fma[1]; fm[4*itemp+2] = fma[2]; fm[4*itemp+3] = fma[3];
+        }
     }
     __device__ __forceinline__ F pfrac(const F* __restrict__ p, const size_t s_eta, const size_t s_prs) const
     {
@@ -644,7 +745,7 @@ constexpr int PL = RRX_PLANCK_PL; // layers per Planck workgroup (64 columns x P
 // The reference recomputes the Planck fraction of the layer below for every level source (16 LUT gathers per
 // cell). Here a workgroup of 64 columns x 8 layers exchanges the fractions through LDS in chunks of 16 g-points,
 // so only the first layer of each workgroup recomputes its neighbour (9 gathers per cell on average).
-template<typename F>
+template<typename F, bool DIRECT = false>
 __global__ void __launch_bounds__(64*PL, RRX_PLANCK_MINWAVES)
 planck_source_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp, const int nPlanckTemp,
@@ -654,7 +755,8 @@ planck_source_kernel(
         const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
         const F temp_ref_min, const F totplnk_delta, const F* __restrict__ totplnk,
         const int* __restrict__ gpoint_flavor,
-        F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac, const int share_on)
+        F* __restrict__ sfc_src, F* __restrict__ lay_src, F* __restrict__ lev_src, F* __restrict__ sfc_src_jac, const int share_on,
+        const F* __restrict__ play, const F* __restrict__ col_gas, const InterpArgs<F> ia)
 {
     extern __shared__ double lds_raw[];
     F* pf = reinterpret_cast<F*>(lds_raw);            // [GCH][PL+1][64]; slot 0 = layer below the workgroup
@@ -680,9 +782,18 @@ planck_source_kernel(
     const size_t s_eta = ntemp, s_prs = size_t(ntemp)*neta, s_gpt = size_t(ntemp)*neta*(npres+1);
     const F delta_Tsurf = F(1.);
 
-    const int itropo = tropo[idx] ? 0 : 1;
     CellInterp<F> own, prev;
-    own.jt = jtemp[idx]; own.jp = jpress[idx] + itropo;
+    int itropo;
+    if constexpr (DIRECT)
+    {
+        own.cs = cell_state<F>(ia, npres, ntemp, play[idx], tlay[idx]);
+        itropo = own.cs.itropo; own.jt = own.cs.jt; own.jp = own.cs.jp_raw + itropo;
+    }
+    else
+    {
+        itropo = tropo[idx] ? 0 : 1;
+        own.jt = jtemp[idx]; own.jp = jpress[idx] + itropo;
+    }
     const bool has_prev = ilay > 0;
     // The layer below the workgroup's first one (its fractions enter lev_src of that first layer) is shared out: every
     // wavefront computes GCH/PL of its g-points per chunk, instead of wavefront 0 doing a second full layer while the
@@ -693,8 +804,16 @@ planck_source_kernel(
     int itropo_m1 = 0;
     if (halo)
     {
-        itropo_m1 = tropo[idx_h] ? 0 : 1;
-        prev.jt = jtemp[idx_h]; prev.jp = jpress[idx_h] + itropo_m1;
+        if constexpr (DIRECT)
+        {
+            prev.cs = cell_state<F>(ia, npres, ntemp, play[idx_h], tlay[idx_h]);
+            itropo_m1 = prev.cs.itropo; prev.jt = prev.cs.jt; prev.jp = prev.cs.jp_raw + itropo_m1;
+        }
+        else
+        {
+            itropo_m1 = tropo[idx_h] ? 0 : 1;
+            prev.jt = jtemp[idx_h]; prev.jp = jpress[idx_h] + itropo_m1;
+        }
     }
     const F t_lay = tlay[idx], t_lev = tlev[idx];
     const bool is_last = ilay == nlay-1;
@@ -718,7 +837,12 @@ planck_source_kernel(
         for (int ig=ig_first; ig<gend; )
         {
             const int fl = gflav[itr*ngpt + ig];
-            if (fl != cur) { cur = fl; ci.load(cell_idx + size_t(fl)*ncl, fmajor, jeta); }
+            if (fl != cur)
+            {
+                cur = fl;
+                if constexpr (DIRECT) ci.load_direct(ia, neta, fl, col_gas, cell_idx, ncl);
+                else ci.load(cell_idx + size_t(fl)*ncl, fmajor, jeta);
+            }
 
             // Shared-cell path: when the 64 columns of the wavefront sit in the same LUT cell for this flavor (the rule at
             // one level of an LES domain), the 8 corners x up to 16 g-points of the band are fetched ONCE per wavefront --
@@ -871,7 +995,12 @@ __global__ void reorder12x21_kernel(const int ni, const int nj, const F* __restr
 
 inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*8)); }
 
-template<typename F, int MODE>
+template<typename F> size_t planck_lds_bytes(const int ngpt)
+{
+    return size_t(GCH)*(PL+1)*64*sizeof(F) + size_t((2*ngpt + 3) & ~3)*sizeof(int) + size_t(PL)*2*4*GCH*2*sizeof(F);
+}
+
+template<typename F, int MODE, bool DIRECT = false>
 int tau_absorption_impl(
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp,
         int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o,
@@ -886,7 +1015,7 @@ int tau_absorption_impl(
         const Bool* tropo, const F* col_mix, const F* fmajor, const F* fminor,
         const F* play, const F* tlay, const F* col_gas, const F* col_dry,
         const int* jeta, const int* jtemp, const int* jpress, const F* krayl,
-        F* tau, F* ssa, F* g, void* stream, const char* name)
+        F* tau, F* ssa, F* g, void* stream, const char* name, const InterpArgs<F> ia = InterpArgs<F>())
 {
     RRX_TRY
     (void)nband; (void)ngas; (void)nflav; (void)band_lims_gpt; (void)nminorklower; (void)nminorkupper;
@@ -897,7 +1026,7 @@ int tau_absorption_impl(
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
-    tau_absorption_kernel<F,MODE><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(
+    tau_absorption_kernel<F,MODE,DIRECT><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
             kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
             minor_scales_with_density_lower, minor_scales_with_density_upper,
@@ -905,7 +1034,7 @@ int tau_absorption_impl(
             idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
             kminor_start_lower, kminor_start_upper,
             tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
-            tau, ssa, g);
+            tau, ssa, g, ia);
     RRX_CATCH(name)
 }
 }  // namespace
@@ -999,6 +1128,76 @@ int rrx_gas_optics_sw_fused##SFX( \
             tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl, \
             tau, ssa, g, stream, "rrx_gas_optics_sw_fused"); \
 } \
+int rrx_gas_optics_lw_direct##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, F* tau, void* stream) \
+{ \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    return tau_absorption_impl<F,2,true>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            (const RrxBool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr, \
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr, \
+            tau, (F*)nullptr, (F*)nullptr, stream, "rrx_gas_optics_lw_direct", ia); \
+} \
+int rrx_gas_optics_sw_direct##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry, const F* krayl, \
+        F* tau, F* ssa, F* g, void* stream) \
+{ \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    return tau_absorption_impl<F,1,true>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            (const RrxBool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, col_dry, \
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, krayl, \
+            tau, ssa, g, stream, "rrx_gas_optics_sw_direct", ia); \
+} \
+int rrx_planck_source_direct##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
+        F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
+        F* sfc_src, F* lay_src, F* lev_src, F* sfc_src_jac, void* stream) \
+{ \
+    RRX_TRY \
+    (void)nbnd; (void)nflav; (void)band_lims_gpt; \
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    planck_source_kernel<F,true><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), planck_lds_bytes<F>(ngpt), static_cast<hipStream_t>(stream)>>>( \
+            ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, (const F*)nullptr, (const int*)nullptr, (const RrxBool*)nullptr, \
+            (const int*)nullptr, (const int*)nullptr, gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, \
+            sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share, play, col_gas, ia); \
+    RRX_CATCH("rrx_planck_source_direct") \
+} \
 int rrx_compute_tau_rayleigh##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
         const int* gpoint_flavor, const int* band_lims_gpt, const F* krayl, \
@@ -1030,9 +1229,10 @@ int rrx_compute_planck_source##SFX( \
     RRX_TRY \
     (void)nbnd; (void)nflav; (void)band_lims_gpt; \
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
-    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), size_t(GCH)*(PL+1)*64*sizeof(F) + size_t((2*ngpt + 3) & ~3)*sizeof(int) + size_t(PL)*2*4*GCH*2*sizeof(F), static_cast<hipStream_t>(stream)>>>( \
+    planck_source_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, PL)), dim3(64, PL), planck_lds_bytes<F>(ngpt), static_cast<hipStream_t>(stream)>>>( \
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, tlay, tlev, tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, \
-            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share); \
+            gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share, \
+            (const F*)nullptr, (const F*)nullptr, InterpArgs<F>()); \
     RRX_CATCH("rrx_compute_planck_source") \
 } \
 int rrx_reorder123x321##SFX(int ni, int nj, int nk, const F* arr_in, F* arr_out, void* stream) \

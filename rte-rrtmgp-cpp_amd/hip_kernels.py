@@ -188,6 +188,42 @@ class HipKernels:
         self._c("gas_optics_sw_fused", *self._absorption_args(kd, it, play, tlay, col_gas), col_dry,
                 it["jeta"], it["jtemp"], it["jpress"], kd.krayl, tau, ssa, g)
 
+    # "direct" forms: interpolation state computed inside the consumer (no intermediate arrays)
+    def _direct_args(self, kd):
+        return (kd.flavor, kd.press_ref_log, kd.temp_ref, float(kd.press_ref_log_delta), float(kd.temp_ref_min),
+                float(kd.temp_ref_delta), float(kd.press_ref_trop_log), kd.vmr_ref)
+
+    def _minor_args(self, kd, play):
+        nlay, ncol = play.shape
+        return (ncol, nlay, kd.nbnd, kd.ngpt, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp,
+                kd.minor_limits_gpt_lower.shape[0], kd.kminor_lower.shape[0],
+                kd.minor_limits_gpt_upper.shape[0], kd.kminor_upper.shape[0], kd.idx_h2o,
+                kd.gpoint_flavor, kd.band_lims_gpt, kd.kmajor, kd.kminor_lower, kd.kminor_upper,
+                kd.minor_limits_gpt_lower, kd.minor_limits_gpt_upper,
+                kd.minor_scales_with_density_lower, kd.minor_scales_with_density_upper,
+                kd.scale_by_complement_lower, kd.scale_by_complement_upper,
+                kd.idx_minor_lower, kd.idx_minor_upper, kd.idx_minor_scaling_lower, kd.idx_minor_scaling_upper,
+                kd.kminor_start_lower, kd.kminor_start_upper)
+
+    def gas_optics_lw_direct(self, kd, play, tlay, col_gas, tau):
+        self._c("gas_optics_lw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, tau)
+        return tau
+
+    def gas_optics_sw_direct(self, kd, play, tlay, col_gas, col_dry, tau, ssa, g):
+        self._c("gas_optics_sw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, col_dry,
+                kd.krayl, tau, ssa, g)
+
+    def planck_source_direct(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, out=None):
+        nlay, ncol = tlay.shape
+        if out is None:
+            out = dict(sfc_src=self.empty((kd.ngpt, ncol)), lay_src=self.empty((kd.ngpt, nlay, ncol)),
+                       lev_src=self.empty((kd.ngpt, nlay+1, ncol)), sfc_src_jac=self.empty((kd.ngpt, ncol)))
+        self._c("planck_source_direct", ncol, nlay, kd.nbnd, kd.ngpt, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp, kd.nPlanckTemp,
+                play, tlay, tlev, tsfc, sfc_lay, col_gas, *self._direct_args(kd),
+                kd.gpoint_bands, kd.band_lims_gpt, kd.planck_frac, float(kd.totplnk_delta), kd.totplnk, kd.gpoint_flavor,
+                out["sfc_src"], out["lay_src"], out["lev_src"], out["sfc_src_jac"])
+        return out
+
     def compute_tau_rayleigh(self, kd, it, col_dry, col_gas):
         nlay, ncol = col_dry.shape
         tr = self.empty((kd.ngpt, nlay, ncol))

@@ -49,25 +49,35 @@ def _sfc_lay(atm):
     return atm.nlay if atm.top_at_1 else 1
 
 
-def gas_state(be, kd, atm, col_dry=None):
-    """col_dry, col_gas and the interpolation state shared by the optical-depth and source kernels."""
+def gas_state(be, kd, atm, col_dry=None, interpolate=True):
+    """col_dry, col_gas and the interpolation state shared by the optical-depth and source kernels. interpolate=False:
+    the consumers compute the interpolation state themselves (the "direct" entry points), nothing is materialised."""
     if col_dry is None:
         col_dry = be.get_col_dry(atm.vmr["h2o"], atm.p_lev)
     col_gas = be.fill_gases(kd, atm.vmr, col_dry)
-    it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+    it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas) if interpolate else None
     return col_dry, col_gas, it
 
 
-def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False):
-    ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
-    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry)
+def _use_direct(be, direct):
+    return hasattr(be, "gas_optics_lw_direct") if direct is None else bool(direct)
 
-    if hasattr(be, "compute_tau_absorption_set"):
-        tau = be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
+
+def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False, direct=None):
+    ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
+    direct = _use_direct(be, direct)
+    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry, interpolate=not direct)
+
+    if direct:          # product default: interpolation recomputed inside the two consumers, no intermediate arrays
+        tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
+        src = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
     else:
-        tau = be.zeros((ngpt, nlay, ncol))
-        be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
-    src = be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm))
+        if hasattr(be, "compute_tau_absorption_set"):
+            tau = be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
+        else:
+            tau = be.zeros((ngpt, nlay, ncol))
+            be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
+        src = be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm))
 
     if cloud_lut is not None:
         tau_cld = be.cloud_optics_1scl(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
@@ -93,19 +103,23 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
     return out
 
 
-def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False):
+def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False, direct=None):
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
-    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry)
-
     if fused_gas is None:
         fused_gas = hasattr(be, "gas_optics_sw_fused")
+    direct = bool(fused_gas) and _use_direct(be, direct)
+    col_dry, col_gas, it = gas_state(be, kd, atm, col_dry, interpolate=not direct)
+
     # clear sky: the asymmetry parameter of the gas optics is identically zero; the HIP entry points take "no g array"
     # natively (nothing written by the gas optics, nothing read by the solver)
     g_zero = bool(fused_gas and cloud_lut is None and getattr(be, "supports_null_g", False))
     if fused_gas:
         tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol))
         g = None if g_zero else be.empty((ngpt, nlay, ncol))
-        be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
+        if direct:
+            be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
+        else:
+            be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
     else:
         tau_abs = be.zeros((ngpt, nlay, ncol))
         be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau_abs)
@@ -157,6 +171,7 @@ class ResidentSolver:
         self.be, self.kd_lw, self.kd_sw, self.atm = be, kd_lw, kd_sw, atm
         self.do_broadband = do_broadband
         self.g_zero = bool(int(os.environ.get("RRX_G_ZERO", "1")))     # clear sky: g == 0 is neither written nor read
+        self.direct = bool(int(os.environ.get("RRX_DIRECT", "1")))     # interpolation state recomputed inside its consumers
         ncol, nlay = atm.ncol, atm.nlay
         ng_l, ng_s = kd_lw.ngpt, kd_sw.ngpt
         e = be.empty
@@ -215,14 +230,19 @@ class ResidentSolver:
             col_dry = self.col_dry2 if (self.overlap and ichain == 1) else self.col_dry
             be._c("get_col_dry", ncol, nlay, atm.vmr["h2o"], atm.p_lev, col_dry)
             col_gas = be.fill_gases(kd, atm.vmr, col_dry)
-            it = be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+            it = None if self.direct else be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
             if kind == "lw":
-                be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                if self.direct:
+                    be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                else:
+                    be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
                 mark("lw_gas_optics", True)
                 mark("lw_planck")
-                be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm),
-                                         out=dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"],
-                                                  sfc_src_jac=buf["sfc_src_jac"]))
+                srcs = dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"], sfc_src_jac=buf["sfc_src_jac"])
+                if self.direct:
+                    be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, out=srcs)
+                else:
+                    be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), out=srcs)
                 mark("lw_planck", True)
                 mark("lw_solver")
                 if self.do_broadband:
@@ -241,7 +261,10 @@ class ResidentSolver:
             else:
                 # clear sky: the asymmetry parameter is identically zero; the fused broadband solver takes "no g" natively
                 gbuf = None if (self.g_zero and self.do_broadband) else buf["g"]
-                be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
+                if self.direct:
+                    be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
+                else:
+                    be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
                 toa = be.spread_col(ncol, kd.solar_source)
                 be.scaling_to_subset(toa, atm.tsi_scaling)
                 mark("sw_gas_optics", True)

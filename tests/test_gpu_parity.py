@@ -464,3 +464,28 @@ def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32):
     print(f"C5 fp32 all-sky {kind}: worst rel err", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     for k, e in worst.items():
         assert e <= (1e-3 if (kind == "sw" and "flux" in k) else 2e-4), f"{kind} {k}: {e:.3e}"
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_direct_gas_optics_equals_interpolation_path(kind, dt, hip_f64, hip_f32):
+    """The "direct" entry points (interpolation state recomputed inside the absorption / Planck kernels) against the
+    reference-shaped sequence rrx_interpolation -> rrx_compute_tau_absorption_set / rrx_gas_optics_sw_fused /
+    rrx_compute_planck_source: the same expressions in the same order, so bit-identical outputs. Real spectral shape,
+    columns spread over both regimes and several LUT cells per wavefront."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    kd0 = synthetic.make_kdist(kind, **REAL_SHAPES[kind])
+    nb = REAL_SHAPES[kind]["nbnd"]
+    atm0 = synthetic.make_atmosphere(200, 140, nbnd_lw=nb, nbnd_sw=nb, seed=9)
+    rng = np.random.default_rng(10)
+    scale = rng.uniform(0.7, 1.3, atm0.ncol)
+    atm0.p_lay = np.ascontiguousarray(atm0.p_lay * scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * scale[None, :])
+    atm0.t_lay = np.ascontiguousarray(atm0.t_lay + rng.uniform(-10, 10, atm0.ncol)[None, :])
+    kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
+    res = []
+    for direct in (False, True):
+        r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, keep=True, direct=direct)
+        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
+    a, b = res
+    for k in ("tau",) + (("lay_src", "lev_src", "sfc_src") if kind == "lw" else ("ssa",)) + ("flux_up", "flux_dn"):
+        assert np.array_equal(a[k], b[k]), f"{kind} {dt} {k}: direct path differs from the interpolation path"
