@@ -201,6 +201,26 @@ int rrx_planck_source_direct##SFX( \
         const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
         F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
         F* sfc_src, F* lay_src, F* lev_src, F* sfc_src_jac, void* stream); \
+/* "Planck-lite" LW chain (what Gas_optics_rrtmgp_gpu::source + Rte_lw_gpu::rte_lw run here in broadband mode): \
+   rrx_planck_fractions writes the Planck fractions pfrac(ncol,nlay,ngpt), the band Planck functions B(tlay)(ncol,nlay,nbnd) and \
+   B(tlev)(ncol,nlay+1,nbnd) and the surface terms -- Planck_source_kernel (gas_optics_rrtmgp_kernels.cu:196-314) without its two \
+   products; rrx_lw_solver_noscat_fractions (one quadrature angle, broadband fluxes) forms lay_source = pfrac*B_lay and \
+   lev_source = sqrt(pfrac*pfrac')*B_lev on the fly; rrx_planck_sources_from_fractions materialises them for any other consumer \
+   (bit-identical to rrx_compute_planck_source). */ \
+int rrx_planck_fractions##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
+        F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
+        F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream); \
+int rrx_planck_sources_from_fractions##SFX(int ncol, int nlay, int ngpt, const int* gpoint_bands, const F* pfrac, const F* blay, \
+        const F* blev, F* lay_src, F* lev_src, void* stream); \
+int rrx_lw_solver_noscat_fractions##SFX( \
+        int ncol, int nlay, int ngpt, RrxBool top_at_1, const F* secants, const F* weights, \
+        const F* tau, const F* pfrac, const F* blay, const F* blev, const int* gpoint_bands, \
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up_loc, F* flux_dn_loc, void* stream); \
 /* ---- Optical_props_kernels_cuda : include_kernels_cuda/optical_props_kernels_cuda.h:33-56 ---- */ \
 int rrx_increment_1scalar_by_1scalar##SFX(int ncol, int nlay, int ngpt, F* tau_inout, const F* tau_in, void* stream); \
 int rrx_increment_2stream_by_2stream##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* ssa_inout, F* g_inout, const F* tau_in, const F* ssa_in, const F* g_in, void* stream); \

@@ -969,6 +969,123 @@ planck_source_kernel(
 }
 
 
+
+// "Planck-lite": the Planck fractions pfrac(col,lay,gpt) (8-point interpolation in planck_frac, as CellInterp::pfrac),
+// the band-integrated Planck functions B(tlay)(col,lay,bnd) and B(tlev)(col,lev,bnd), and the surface terms -- everything
+// Planck_source_kernel (gas_optics_rrtmgp_kernels.cu:196-314) computes EXCEPT the two products lay_source = pfrac*B_lay and
+// lev_source = sqrt(pfrac*pfrac')*B_lev, which the broadband LW solver forms itself (rrx_lw_solver_noscat_fractions) or
+// rrx_planck_sources_from_fractions materialises for anybody else. One (col,lay,gpt) array written instead of two, no
+// neighbour-layer exchange. One thread per cell, lanes = 64 consecutive columns, interpolation state computed in place.
+template<typename F>
+__global__ void __launch_bounds__(256)
+planck_fraction_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp, const int nPlanckTemp,
+        const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ tlev, const F* __restrict__ tsfc, const int sfc_lay,
+        const F* __restrict__ col_gas, const InterpArgs<F> ia,
+        const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
+        const F totplnk_delta, const F* __restrict__ totplnk, const int* __restrict__ gpoint_flavor,
+        F* __restrict__ pfrac_out, F* __restrict__ blay_out, F* __restrict__ blev_out,
+        F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac)
+{
+    extern __shared__ int lds_gflav[];                       // [2][ngpt] flavor (0-based) per regime and g-point
+    for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*blockDim.y)
+        lds_gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
+    __syncthreads();
+
+    const int icol = blockIdx.x*64 + threadIdx.x;
+    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    if (icol >= ncol || ilay >= nlay) return;
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t ncv = size_t(ncol)*(nlay+1);
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const unsigned s_eta = ntemp, s_prs = unsigned(ntemp)*neta;
+    const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
+    constexpr unsigned SZ = sizeof(F);
+
+    CellInterp<F> ci;
+    ci.cs = cell_state<F>(ia, npres, ntemp, play[idx], tlay[idx]);
+    const int itropo = ci.cs.itropo;
+    ci.jt = ci.cs.jt; ci.jp = ci.cs.jp_raw + itropo;
+    const F t_lay = tlay[idx], t_lev = tlev[idx];
+    const bool is_last = ilay == nlay-1;
+    const bool is_sfc = ilay == sfc_lay-1;
+    const F t_levp = tlev[idx + ncol];
+    const F t_sfc = tsfc[icol];
+
+    int cur_flav = -1, cur_bnd = -1;
+    F b_sfc = 0, b_sfc2 = 0;
+    unsigned b0 = 0, b1 = 0;           // byte offsets of the (jt-1 | jt) pairs at (je0, jp-1) and (je1, jp-1)
+    bool same_eta = false;
+    constexpr int PG = 4;              // g-points whose gathers are in flight together
+
+    for (int ig=0; ig<ngpt; )
+    {
+        const int fl = lds_gflav[itropo*ngpt + ig];
+        if (fl != cur_flav)
+        {
+            cur_flav = fl;
+            ci.load_direct(ia, neta, fl, col_gas, idx, ncl);
+            b0 = unsigned((ci.jt-1) + (ci.je[0]-1)*s_eta + (ci.jp-1)*s_prs)*SZ;
+            b1 = unsigned( ci.jt    + (ci.je[1]-1)*s_eta + (ci.jp-1)*s_prs)*SZ;
+            same_eta = (ci.je[0] == ci.je[1]);
+        }
+        int ge = min(ig + PG, ngpt);
+        #pragma unroll
+        for (int u=PG-1; u>=1; --u)
+            if (ig + u < ngpt && lds_gflav[itropo*ngpt + ig + u] != fl) ge = ig + u;
+
+        F v[PG][8];
+        #pragma unroll
+        for (int u=0; u<PG; ++u)
+        {
+            const F* p = pfracin + size_t(min(ig + u, ge-1))*s_gpt;
+            const Pair<F> p0 = ld2(p, b0), p1 = ld2(p, b0 + s_eta*SZ), p2 = ld2(p, b0 + s_prs*SZ), p3 = ld2(p, b0 + (s_prs + s_eta)*SZ);
+            v[u][0] = p0.x; v[u][1] = p1.x; v[u][2] = p2.x; v[u][3] = p3.x;
+            v[u][4] = p0.y; v[u][5] = p1.y; v[u][6] = p2.y; v[u][7] = p3.y;
+        }
+        if (!same_eta)
+        {
+            #pragma unroll
+            for (int u=0; u<PG; ++u)
+            {
+                const F* p = pfracin + size_t(min(ig + u, ge-1))*s_gpt;
+                v[u][4] = ld(p, b1); v[u][5] = ld(p, b1 + s_eta*SZ); v[u][6] = ld(p, b1 + s_prs*SZ); v[u][7] = ld(p, b1 + (s_prs + s_eta)*SZ);
+            }
+        }
+        #pragma unroll
+        for (int u=0; u<PG; ++u)
+        {
+            const int g = ig + u;
+            if (g < ge)
+            {
+                const F pfrac = (ci.fm[0]*v[u][0] + ci.fm[1]*v[u][1] + ci.fm[2]*v[u][2] + ci.fm[3]*v[u][3])
+                              + (ci.fm[4]*v[u][4] + ci.fm[5]*v[u][5] + ci.fm[6]*v[u][6] + ci.fm[7]*v[u][7]);
+                pfrac_out[idx + size_t(g)*ncl] = pfrac;
+                const int ibnd = gpoint_bands[g] - 1;
+                if (ibnd != cur_bnd)
+                {
+                    cur_bnd = ibnd;
+                    const F* tp = totplnk + size_t(ibnd)*nPlanckTemp;
+                    blay_out[idx + size_t(ibnd)*ncl] = interp1d(t_lay, ia.temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                    blev_out[idx + size_t(ibnd)*ncv] = interp1d(t_lev, ia.temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                    if (is_last) blev_out[idx + ncol + size_t(ibnd)*ncv] = interp1d(t_levp, ia.temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                    if (is_sfc)
+                    {
+                        b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                        b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, totplnk_delta, nPlanckTemp, tp);
+                    }
+                }
+                if (is_sfc)
+                {
+                    sfc_src    [icol + size_t(g)*ncol] = pfrac * b_sfc;
+                    sfc_src_jac[icol + size_t(g)*ncol] = pfrac * (b_sfc2 - b_sfc);
+                }
+            }
+        }
+        ig = ge;
+    }
+}
+
 template<typename F>
 __global__ void reorder123x321_kernel(const int ni, const int nj, const int nk, const F* __restrict__ in, F* __restrict__ out)
 {
@@ -1197,6 +1314,24 @@ int rrx_planck_source_direct##SFX( \
             (const int*)nullptr, (const int*)nullptr, gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, \
             sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share, play, col_gas, ia); \
     RRX_CATCH("rrx_planck_source_direct") \
+} \
+int rrx_planck_fractions##SFX( \
+        int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
+        F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
+        F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream) \
+{ \
+    RRX_TRY \
+    (void)nbnd; (void)nflav; (void)band_lims_gpt; \
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem"); \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    planck_fraction_kernel<F><<<dim3(rrx::ceil_div(ncol, 64), rrx::ceil_div(nlay, 4)), dim3(64, 4), size_t(2)*ngpt*sizeof(int), static_cast<hipStream_t>(stream)>>>( \
+            ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin, \
+            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac); \
+    RRX_CATCH("rrx_planck_fractions") \
 } \
 int rrx_compute_tau_rayleigh##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \

@@ -328,6 +328,262 @@ lw_noscat_scan_kernel(
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused broadband form, second generation (round 2). Same tiling and scans as lw_noscat_scan_kernel<..., BB = true>, plus
+//   PRE  : software pipeline over the g-point loop -- the loads of g-point g+1 are requested behind the first scan barrier
+//          of g-point g and land during its scans and replays (tools/lw_lab.hip: 2.78 -> 2.59 ms at C4 fp64);
+//   LITE : "Planck-lite" inputs. Instead of lay_source and lev_source the kernel reads the Planck fractions pfrac(col,lay,gpt)
+//          and the band-integrated Planck functions B_lay(col,lay,bnd), B_lev(col,lev,bnd), and rebuilds
+//          lay_source = pfrac*B_lay, lev_source = sqrt(pfrac*pfrac')*B_lev (first and last level: pfrac*B_lev) itself,
+//          exactly the expressions of Planck_source_kernel (gas_optics_rrtmgp_kernels.cu:196-314). Two cell arrays read per
+//          g-point instead of three, and the Planck kernel writes one instead of two (LW chain at C4: 9.9 -> 7.5 ms).
+//          The band's B values sit in per-thread LDS columns and are refreshed when the band changes.
+// One quadrature angle, no Jacobian (the general kernel above keeps those).
+template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, int EV = 2>
+__global__ void __launch_bounds__(256, 2)
+lw_noscat_bb_kernel(
+        const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* __restrict__ secants, const F* __restrict__ weights,
+        const F* __restrict__ tau, const F* __restrict__ lay_source /* or pfrac */, const F* __restrict__ lev_source,
+        const F* __restrict__ blay, const F* __restrict__ blev, const int* __restrict__ gpoint_bands,
+        const F* __restrict__ sfc_emis, const F* __restrict__ sfc_src, const F* __restrict__ inc_flux,
+        F* __restrict__ flux_up, F* __restrict__ flux_dn)
+{
+    constexpr int CL = CLT, LL = 64/CLT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & (CL-1), ll = lane / CL;
+    const int h = wave % W, w0 = wave - h;
+    const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
+    __shared__ F xch[4*V][4][CL];
+    __shared__ F lds_b[LITE ? (2*K+1)*V : 1][256];       // per-thread columns: B_lay[K], B_lev[K+1] of the current band
+    int icol = wave_col0 + cl*V;
+    const bool active = icol < ncol;
+    if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;
+    const bool writer = active && wave_col0 < ncol;
+    const int nlev = nlay + 1;
+    const size_t ncl = size_t(ncol);
+    const int t0 = (h*LL + ll)*K;
+    const F pi = F(3.14159265358979323846);
+    const F tau_thres = sqrt(sqrt(Lim<F>::eps()));
+
+    F acc_up[K][V], acc_dn[K][V];
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+        #pragma unroll
+        for (int v=0; v<V; ++v) { acc_up[j][v] = F(0.); acc_dn[j][v] = F(0.); }
+
+    // element offsets inside one g-point slab: sweep layer s = t0+j, sweep level t = t0+j (clamped into the domain)
+    auto lay_off = [&](const int j) -> unsigned
+    {
+        const int sc = min(max(t0 + j, 0), nlay-1);
+        return unsigned(top_at_1 ? sc : nlay-1-sc)*unsigned(ncol) + unsigned(icol);
+    };
+    auto lev_off = [&](const int j) -> unsigned
+    {
+        const int tc = min(t0 + j, nlay);
+        return unsigned(top_at_1 ? tc : nlay-tc)*unsigned(ncol) + unsigned(icol);
+    };
+
+    struct Loads { Vec<F,V> a0[K], a1[K], a2[LITE ? 1 : K], x_next, x_prev, emis, ssrc, D, inc; };
+    auto issue = [&](const int g, Loads& L)
+    {
+        const F* __restrict__ t_g = tau + size_t(g)*ncl*nlay;
+        const F* __restrict__ l_g = lay_source + size_t(g)*ncl*nlay;
+        #pragma unroll
+        for (int j=0; j<K; ++j) { const unsigned o = lay_off(j); L.a0[j] = load_cols<F,V>(t_g + o); L.a1[j] = load_cols<F,V>(l_g + o); }
+        if constexpr (!LITE)
+        {
+            const F* __restrict__ v_g = lev_source + size_t(g)*ncl*nlev;
+            #pragma unroll
+            for (int j=0; j<K; ++j) L.a2[j] = load_cols<F,V>(v_g + lev_off(j));
+            L.x_next = load_cols<F,V>(v_g + lev_off(K));          // level below the lane's last layer
+        }
+        else
+        {
+            L.x_next = load_cols<F,V>(l_g + lay_off(K));          // pfrac of the layer below the lane's last one
+            L.x_prev = load_cols<F,V>(l_g + lay_off(-1));         // pfrac of the layer above the lane's first one
+        }
+        const size_t sfc = size_t(g)*ncl + icol;
+        L.emis = load_cols<F,V>(sfc_emis + sfc); L.ssrc = load_cols<F,V>(sfc_src + sfc); L.D = load_cols<F,V>(secants + sfc);
+        if (inc_flux != nullptr) L.inc = load_cols<F,V>(inc_flux + sfc);
+    };
+
+    Loads nxt;
+    if constexpr (PRE) issue(0, nxt);
+    int cur_bnd = -1;
+    const F wgt = weights[0];
+    const F scale = pi * wgt;
+
+    for (int igpt=0; igpt<ngpt; ++igpt)
+    {
+    if constexpr (!PRE) __syncthreads();        // partner waves issue their load bursts together
+    Loads cur;
+    if constexpr (PRE) cur = nxt; else issue(igpt, cur);
+
+    if constexpr (LITE)
+    {
+        const int ib = gpoint_bands[igpt] - 1;                  // wave-uniform
+        if (ib != cur_bnd)
+        {
+            cur_bnd = ib;
+            const F* __restrict__ bl = blay + size_t(ib)*ncl*nlay;
+            const F* __restrict__ bv = blev + size_t(ib)*ncl*nlev;
+            #pragma unroll
+            for (int j=0; j<K; ++j)
+            {
+                const Vec<F,V> x = load_cols<F,V>(bl + lay_off(j));
+                #pragma unroll
+                for (int v=0; v<V; ++v) lds_b[j*V+v][tid] = x.v[v];
+            }
+            #pragma unroll
+            for (int j=0; j<=K; ++j)
+            {
+                const Vec<F,V> x = load_cols<F,V>(bv + lev_off(j));
+                #pragma unroll
+                for (int v=0; v<V; ++v) lds_b[(K+j)*V+v][tid] = x.v[v];
+            }
+        }
+    }
+
+    // level source at sweep level t0+j for column v
+    auto level_src = [&](const int j, const int v) -> F
+    {
+        if constexpr (!LITE) return (j < K) ? cur.a2[min(j, K-1)].v[v] : cur.x_next.v[v];
+        else
+        {
+            const int t = t0 + j;
+            const F pa = (j == 0) ? cur.x_prev.v[v] : cur.a1[max(j-1, 0)].v[v];
+            const F pb = (j == K) ? cur.x_next.v[v] : cur.a1[min(j, K-1)].v[v];
+            const F bvv = lds_b[(K+j)*V+v][tid];
+            if (t <= 0) return pb * bvv;
+            if (t >= nlay) return pa * bvv;
+            return sqrt_pos(pa*pb) * bvv;
+        }
+    };
+
+    F tr[K][V], sdn[K][V], sup[K][V];
+    F A[V], Bdn[V], Bup[V], lva[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v) { A[v] = F(1.); Bdn[v] = F(0.); Bup[v] = F(0.); lva[v] = level_src(0, v); }
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const bool valid = (t0 + j) < nlay;
+        #pragma unroll
+        for (int v=0; v<V; ++v)
+        {
+            F tvj = cur.a0[j].v[v];
+            const int e = j*V + v - EV*V;                      // at most EV layers of evaluations in flight
+            if (e >= 0) asm volatile("" : "+v"(tvj) : "v"(sup[e / V][e % V]));
+            const F lvb = level_src(j+1, v);
+            F lsj = cur.a1[j].v[v];
+            if constexpr (LITE) lsj *= lds_b[j*V+v][tid];
+            const F tau_loc = tvj * cur.D.v[v];
+            const F trans = exp_neg(-tau_loc);
+            const F fact = tau_loc > tau_thres ? (F(1.) - trans) * fast_rcp(tau_loc) - trans
+                                               : tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
+            const F omt = F(1.) - trans;
+            const F s_dn = omt * lvb + F(2.) * fact * (lsj - lvb);
+            const F s_up = omt * lva[v] + F(2.) * fact * (lsj - lva[v]);
+            lva[v] = lvb;
+            tr[j][v] = valid ? trans : F(1.); sdn[j][v] = valid ? s_dn : F(0.); sup[j][v] = valid ? s_up : F(0.);
+            Bdn[v] = tr[j][v]*Bdn[v] + sdn[j][v];
+            Bup[v] += A[v]*sup[j][v];
+            A[v] *= tr[j][v];
+        }
+    }
+
+    F dn_in[V], up_in[V];
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        // ---- downward: inclusive scan over the level-lanes, then over the waves of the column group
+        F a = A[v], b = Bdn[v];
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(a, lane - d*CL), b2 = shfl(b, lane - d*CL);
+            if (ll >= d) { b = a*b2 + b; a = a*a2; }
+        }
+        F xa = F(1.), xb = F(0.);
+        if (ll == LL-1) { xch[4*v+0][wave][cl] = a; xch[4*v+1][wave][cl] = b; }
+        __syncthreads();
+        if constexpr (PRE)
+        {
+            if (v == 0)
+            {
+                // every wave of the workgroup is here: the waves that share 128-B lines ask for them together
+                __builtin_amdgcn_sched_barrier(0);
+                issue(min(igpt + 1, ngpt - 1), nxt);            // (last iteration: a harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        F fa = F(1.), fb = F(0.);
+        #pragma unroll
+        for (int w=0; w<W; ++w)
+        {
+            const F oa = xch[4*v+0][w0+w][cl], ob = xch[4*v+1][w0+w][cl];
+            if (w == h) { xa = fa; xb = fb; }
+            fb = oa*fb + ob; fa = oa*fa;
+        }
+        if (h > 0) { b = a*xb + b; a = a*xa; }
+        F ae = shfl(a, lane - CL), be = shfl(b, lane - CL);
+        if (ll == 0) { ae = xa; be = xb; }
+        const F dn_top = (inc_flux != nullptr) ? cur.inc.v[v] / pi : F(0.);
+        dn_in[v] = ae*dn_top + be;
+        const F dn_sfc = fa*dn_top + fb;
+        const F up_sfc = dn_sfc * (F(1.) - cur.emis.v[v]) + cur.emis.v[v] * cur.ssrc.v[v];
+
+        // ---- upward: inclusive suffix scan
+        a = A[v]; b = Bup[v];
+        #pragma unroll
+        for (int d=1; d<LL; d<<=1)
+        {
+            const F a2 = shfl(a, lane + d*CL), b2 = shfl(b, lane + d*CL);
+            if (ll + d < LL) { b = a*b2 + b; a = a*a2; }
+        }
+        xa = F(1.); xb = F(0.);
+        if (ll == 0) { xch[4*v+2][wave][cl] = a; xch[4*v+3][wave][cl] = b; }
+        __syncthreads();
+        #pragma unroll
+        for (int w=W-1; w>=1; --w)
+            if (w > h) { const F oa = xch[4*v+2][w0+w][cl], ob = xch[4*v+3][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
+        if (h < W-1) { b = a*xb + b; a = a*xa; }
+        ae = shfl(a, lane + CL); be = shfl(b, lane + CL);
+        if (ll == LL-1) { ae = xa; be = xb; }
+        up_in[v] = ae*up_sfc + be;
+    }
+
+    #pragma unroll
+    for (int v=0; v<V; ++v)
+    {
+        F dn = dn_in[v];
+        #pragma unroll
+        for (int j=0; j<K; ++j) { add_rounded(acc_dn[j][v], scale*dn); dn = tr[j][v]*dn + sdn[j][v]; }
+        F up = up_in[v];
+        #pragma unroll
+        for (int j=K-1; j>=0; --j) { up = tr[j][v]*up + sup[j][v]; add_rounded(acc_up[j][v], scale*up); }
+    }
+    }   // g-point loop
+
+    if (!writer) return;
+    #pragma unroll
+    for (int j=0; j<K; ++j)
+    {
+        const int t = t0 + j;
+        if (t <= nlay)
+        {
+            const size_t o = size_t(icol) + size_t(top_at_1 ? t : nlay - t)*ncl;
+            Vec<F,V> u, d;
+            #pragma unroll
+            for (int v=0; v<V; ++v) { u.v[v] = acc_up[j][v]; d.v[v] = acc_dn[j][v]; }
+            store_cols<F,V>(flux_up + o, u);
+            store_cols<F,V>(flux_dn + o, d);
+        }
+    }
+}
+
 // Any-nlay fallback: one thread per (col, gpt), layer quantities recomputed in the second sweep
 // (no scratch). Used when nlay+1 > 8*K_MAX, and as the A/B baseline in bench.py --variant serial.
 template<typename F, bool JAC, bool ACC>
@@ -511,6 +767,57 @@ bool launch_scan_bb16(
 }
 
 
+
+// second-generation fused broadband kernel (lw_noscat_bb_kernel); LITE: lay_source = pfrac, lev_source unused
+template<typename F, int V, int W, int CLT, bool LITE>
+bool launch_bb2(
+        hipStream_t st, const bool pre, const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* blay, const F* blev, const int* gpoint_bands,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
+{
+    if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
+    const dim3 grid(ceil_div(ncol, (4/W)*CLT*V), 1);
+    const int need = ceil_div(nlay+1, (64/CLT)*W);
+#define RRX_LW_B2(KK) if (need <= KK) { \
+        if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn); \
+        else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn); \
+        return true; }
+    if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
+    else                     { RRX_LW_B2(2) RRX_LW_B2(3) RRX_LW_B2(5) }
+#undef RRX_LW_B2
+    return false;
+}
+
+// broadband fluxes from tau + (lay_source, lev_source) [LITE = false] or tau + Planck fractions and band Planck functions
+// [LITE = true] in the one-kernel form; false when the shape is outside its tilings (the caller takes another path)
+template<typename F, bool LITE>
+bool lw_fused_broadband(
+        hipStream_t st, const int ncol, const int nlay, const int ngpt, const int top_at_1,
+        const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
+        const F* blay, const F* blev, const int* gpoint_bands,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
+{
+    const bool pre = tuning().lw_variant != 13;                 // 13: without the pipelined loads (A/B runs)
+    if constexpr (sizeof(F) == 8)
+        return launch_bb2<F,1,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
+    else
+    {
+        if (ncol % 4 == 0 &&
+            launch_bb2<F,4,4,8,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                     blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        if (ncol % 2 == 0 &&
+            launch_bb2<F,2,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        return false;
+    }
+}
+
 #define RRX_LW_ARGS_CALL ncol, nlay, ngpt, top_at_1, imu, secants, weights, tau, lay_source, lev_source, \
         sfc_emis, sfc_src, inc_flux, up, dn, sfc_src_jac, flux_up_jac
 
@@ -540,6 +847,12 @@ int lw_solver_noscat_impl(
         && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
+        // default: the second-generation kernel (pipelined loads); variants 8 / 9 / 12 keep the first-generation tilings
+        if ((g_lw_variant == 0 || g_lw_variant == 13) &&
+            lw_fused_broadband<F,false>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                        (const F*)nullptr, (const F*)nullptr, (const int*)nullptr, sfc_emis, sfc_src, inc_flux,
+                                        flux_up_loc, flux_dn_loc))
+            return 0;
         // four waves per column group (K = 5 at 140 layers) leave room for the g-point sums AND 128-B row segments.
         // Measured at C4: fp32 2.15 ms against 2.28 ms with two waves / 64-B rows; fp64 3.94 against 3.15 ms (256 VGPRs,
         // 12 % idle level-lanes), so fp64 keeps two waves unless variant 9 asks for four.
@@ -610,6 +923,76 @@ int lw_solver_noscat_impl(
     }
     RRX_CATCH("rrx_lw_solver_noscat")
 }
+
+template<typename F>
+__global__ void planck_sources_from_fractions_kernel(
+        const int ncol, const int nlay, const int ngpt, const int* __restrict__ gpoint_bands,
+        const F* __restrict__ pf, const F* __restrict__ blay, const F* __restrict__ blev,
+        F* __restrict__ lay_src, F* __restrict__ lev_src)
+{
+    // lay_source = pfrac*B_lay; lev_source(level m) = sqrt(pfrac(m)*pfrac(m-1))*B_lev(m), first / last level pfrac*B_lev:
+    // the expressions (and rounding) of Planck_source_kernel, gas_optics_rrtmgp_kernels.cu:260-306
+    const size_t ncl = ncol; const int nlev = nlay+1;
+    const size_t n = ncl*nlev*ngpt;
+    for (size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x)*blockDim.x)
+    {
+        const int icol = int(i % ncl), m = int((i / ncl) % nlev), ig = int(i / (ncl*nlev));
+        const int ib = gpoint_bands[ig] - 1;
+        const size_t lb = size_t(ig)*ncl*nlay + icol;
+        const F bl = blev[(size_t(ib)*nlev + m)*ncl + icol];
+        F v;
+        if (m == 0) v = pf[lb] * bl;
+        else if (m == nlay) v = pf[lb + size_t(nlay-1)*ncl] * bl;
+        else v = sqrt(pf[lb + size_t(m)*ncl] * pf[lb + size_t(m-1)*ncl]) * bl;
+        lev_src[i] = v;
+        if (m < nlay) lay_src[lb + size_t(m)*ncl] = pf[lb + size_t(m)*ncl] * blay[(size_t(ib)*nlay + m)*ncl + icol];
+    }
+}
+
+template<typename F>
+int planck_sources_from_fractions_impl(int ncol, int nlay, int ngpt, const int* gpoint_bands, const F* pfrac, const F* blay,
+        const F* blev, F* lay_src, F* lev_src, void* stream)
+{
+    RRX_TRY
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+    const size_t n = size_t(ncol)*(nlay+1)*ngpt;
+    planck_sources_from_fractions_kernel<F><<<int(std::min<size_t>((n + 255)/256, 256*16)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            ncol, nlay, ngpt, gpoint_bands, pfrac, blay, blev, lay_src, lev_src);
+    RRX_CATCH("rrx_planck_sources_from_fractions")
+}
+
+template<typename F>
+int lw_solver_noscat_fractions_impl(
+        const int ncol, const int nlay, const int ngpt, const Bool top_at_1,
+        const F* secants, const F* weights, const F* tau, const F* pfrac, const F* blay, const F* blev, const int* gpoint_bands,
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up_loc, F* flux_dn_loc, void* stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        RRX_TRY
+        if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+        if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
+        constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+        const int var = tuning().lw_variant;
+        if ((var == 0 || var == 13) && ceil_div(ncol, CL*VBB) >= tuning().bb_min_groups &&
+            lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
+                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
+            return check_launch("rrx_lw_solver_noscat_fractions");
+        } catch (const std::exception& e) { rrx::set_error(std::string("rrx_lw_solver_noscat_fractions: ") + e.what()); return 1; }
+    }
+    // outside the one-kernel form (few columns, very tall columns, A/B variants): rebuild the sources and take the general entry
+    F* lay = nullptr; F* lev = nullptr;
+    const size_t n_lay = size_t(ncol)*nlay*ngpt, n_lev = size_t(ncol)*(nlay+1)*ngpt;
+    if (hipMallocAsync(reinterpret_cast<void**>(&lay), (n_lay + n_lev)*sizeof(F), st) != hipSuccess)
+    { rrx::set_error("rrx_lw_solver_noscat_fractions: workspace allocation failed"); return 1; }
+    lev = lay + n_lay;
+    int rc = planck_sources_from_fractions_impl<F>(ncol, nlay, ngpt, gpoint_bands, pfrac, blay, blev, lay, lev, stream);
+    if (rc == 0)
+        rc = lw_solver_noscat_impl<F>(ncol, nlay, ngpt, top_at_1, 1, secants, weights, tau, lay, lev, sfc_emis, sfc_src, inc_flux,
+                                      (F*)nullptr, (F*)nullptr, Bool(1), flux_up_loc, flux_dn_loc, Bool(0), (const F*)nullptr, (F*)nullptr, stream);
+    (void)hipFreeAsync(lay, st);
+    return rc;
+}
 }  // namespace
 
 
@@ -660,4 +1043,20 @@ int rrx_lw_solver_noscat_f32(
             sfc_emis, sfc_src, inc_flux, flux_up, flux_dn, do_broadband, flux_up_loc, flux_dn_loc,
             do_jacobians, sfc_src_jac, flux_up_jac, stream);
 }
+
+#define RRX_DEFINE_LW_FRACTIONS(F, SFX) \
+int rrx_lw_solver_noscat_fractions##SFX( \
+        int ncol, int nlay, int ngpt, Bool top_at_1, const F* secants, const F* weights, \
+        const F* tau, const F* pfrac, const F* blay, const F* blev, const int* gpoint_bands, \
+        const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up_loc, F* flux_dn_loc, void* stream) \
+{ \
+    return lw_solver_noscat_fractions_impl<F>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, blay, blev, gpoint_bands, \
+            sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc, stream); \
+} \
+int rrx_planck_sources_from_fractions##SFX(int ncol, int nlay, int ngpt, const int* gpoint_bands, const F* pfrac, const F* blay, \
+        const F* blev, F* lay_src, F* lev_src, void* stream) \
+{ return planck_sources_from_fractions_impl<F>(ncol, nlay, ngpt, gpoint_bands, pfrac, blay, blev, lay_src, lev_src, stream); }
+
+RRX_DEFINE_LW_FRACTIONS(double, _f64)
+RRX_DEFINE_LW_FRACTIONS(float, _f32)
 }

@@ -224,6 +224,33 @@ class HipKernels:
                 out["sfc_src"], out["lay_src"], out["lev_src"], out["sfc_src_jac"])
         return out
 
+    # "Planck-lite" LW chain: fractions + band Planck functions, sources formed inside the broadband solver
+    def planck_fractions(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, out=None):
+        nlay, ncol = tlay.shape
+        if out is None:
+            out = dict(pfrac=self.empty((kd.ngpt, nlay, ncol)), blay=self.empty((kd.nbnd, nlay, ncol)),
+                       blev=self.empty((kd.nbnd, nlay+1, ncol)), sfc_src=self.empty((kd.ngpt, ncol)), sfc_src_jac=self.empty((kd.ngpt, ncol)))
+        self._c("planck_fractions", ncol, nlay, kd.nbnd, kd.ngpt, kd.ngas, kd.nflav, kd.neta, kd.npres, kd.ntemp, kd.nPlanckTemp,
+                play, tlay, tlev, tsfc, sfc_lay, col_gas, *self._direct_args(kd),
+                kd.gpoint_bands, kd.band_lims_gpt, kd.planck_frac, float(kd.totplnk_delta), kd.totplnk, kd.gpoint_flavor,
+                out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"])
+        return out
+
+    def planck_sources_from_fractions(self, kd, fr, lay_src=None, lev_src=None):
+        ngpt, nlay, ncol = fr["pfrac"].shape
+        lay_src = self.empty((ngpt, nlay, ncol)) if lay_src is None else lay_src
+        lev_src = self.empty((ngpt, nlay+1, ncol)) if lev_src is None else lev_src
+        self._c("planck_sources_from_fractions", ncol, nlay, ngpt, kd.gpoint_bands, fr["pfrac"], fr["blay"], fr["blev"], lay_src, lev_src)
+        return lay_src, lev_src
+
+    def lw_solver_noscat_fractions(self, top_at_1, kd, secants, weights, tau, fr, sfc_emis, inc_flux=None, flux_up=None, flux_dn=None):
+        ngpt, nlay, ncol = tau.shape
+        flux_up = self.empty((nlay+1, ncol)) if flux_up is None else flux_up
+        flux_dn = self.empty((nlay+1, ncol)) if flux_dn is None else flux_dn
+        self._c("lw_solver_noscat_fractions", ncol, nlay, ngpt, BoolArg(top_at_1), secants, weights, tau,
+                fr["pfrac"], fr["blay"], fr["blev"], kd.gpoint_bands, sfc_emis, fr["sfc_src"], inc_flux, flux_up, flux_dn)
+        return dict(flux_up=flux_up, flux_dn=flux_dn)
+
     def compute_tau_rayleigh(self, kd, it, col_dry, col_gas):
         nlay, ncol = col_dry.shape
         tr = self.empty((kd.ngpt, nlay, ncol))

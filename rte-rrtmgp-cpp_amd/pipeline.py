@@ -63,14 +63,25 @@ def _use_direct(be, direct):
     return hasattr(be, "gas_optics_lw_direct") if direct is None else bool(direct)
 
 
-def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False, direct=None):
+def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False, direct=None, lite=None):
+    """lite (default: broadband mode with one angle on a backend that has it): Planck fractions + band Planck functions, the
+    sources are formed inside the broadband solver (the "Planck-lite" chain); keep=True materialises them for the caller."""
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
     direct = _use_direct(be, direct)
+    if lite is None:
+        lite = direct and do_broadband and n_gauss_angles == 1 and hasattr(be, "planck_fractions")
     col_dry, col_gas, it = gas_state(be, kd, atm, col_dry, interpolate=not direct)
 
+    fr = None
     if direct:          # product default: interpolation recomputed inside the two consumers, no intermediate arrays
         tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
-        src = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
+        if lite:
+            fr = be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
+            src = dict(sfc_src=fr["sfc_src"], sfc_src_jac=fr["sfc_src_jac"], lay_src=None, lev_src=None)
+            if keep:
+                src["lay_src"], src["lev_src"] = be.planck_sources_from_fractions(kd, fr)
+        else:
+            src = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
     else:
         if hasattr(be, "compute_tau_absorption_set"):
             tau = be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
@@ -88,8 +99,11 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
     weights = be.asarray(np.ascontiguousarray(GAUSS_WTS[n_gauss_angles-1, :n_gauss_angles]))
     secants = be.lw_secants_array(ncol, ngpt, n_gauss_angles, MAX_GAUSS_PTS, gauss_Ds)
 
-    r = be.lw_solver_noscat(atm.top_at_1, secants, weights, tau, src["lay_src"], src["lev_src"],
-                            sfc_emis_gpt, src["sfc_src"], None, do_broadband=do_broadband)
+    if fr is not None:
+        r = be.lw_solver_noscat_fractions(atm.top_at_1, kd, secants, weights, tau, fr, sfc_emis_gpt)
+    else:
+        r = be.lw_solver_noscat(atm.top_at_1, secants, weights, tau, src["lay_src"], src["lev_src"],
+                                sfc_emis_gpt, src["sfc_src"], None, do_broadband=do_broadband)
     if do_broadband:
         flux_up, flux_dn = r["flux_up"], r["flux_dn"]
     else:
@@ -172,12 +186,18 @@ class ResidentSolver:
         self.do_broadband = do_broadband
         self.g_zero = bool(int(os.environ.get("RRX_G_ZERO", "1")))     # clear sky: g == 0 is neither written nor read
         self.direct = bool(int(os.environ.get("RRX_DIRECT", "1")))     # interpolation state recomputed inside its consumers
+        # broadband mode: Planck fractions + band Planck functions, sources formed inside the LW solver ("Planck-lite" chain)
+        self.lite = self.direct and do_broadband and bool(int(os.environ.get("RRX_LITE", "1")))
         ncol, nlay = atm.ncol, atm.nlay
         ng_l, ng_s = kd_lw.ngpt, kd_sw.ngpt
         e = be.empty
         self.col_dry = e((nlay, ncol))
-        self.lw = dict(tau=e((ng_l, nlay, ncol)), lay_src=e((ng_l, nlay, ncol)), lev_src=e((ng_l, nlay+1, ncol)),
-                       sfc_src=e((ng_l, ncol)), sfc_src_jac=e((ng_l, ncol)))
+        if self.lite:
+            self.lw = dict(tau=e((ng_l, nlay, ncol)), pfrac=e((ng_l, nlay, ncol)), blay=e((kd_lw.nbnd, nlay, ncol)),
+                           blev=e((kd_lw.nbnd, nlay+1, ncol)), sfc_src=e((ng_l, ncol)), sfc_src_jac=e((ng_l, ncol)))
+        else:
+            self.lw = dict(tau=e((ng_l, nlay, ncol)), lay_src=e((ng_l, nlay, ncol)), lev_src=e((ng_l, nlay+1, ncol)),
+                           sfc_src=e((ng_l, ncol)), sfc_src_jac=e((ng_l, ncol)))
         self.sw = dict(tau=e((ng_s, nlay, ncol)), ssa=e((ng_s, nlay, ncol)), g=e((ng_s, nlay, ncol)))
         if not do_broadband:
             self.lw.update(gpt_up=e((ng_l, nlay+1, ncol)), gpt_dn=e((ng_l, nlay+1, ncol)))
@@ -238,14 +258,19 @@ class ResidentSolver:
                     be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
                 mark("lw_gas_optics", True)
                 mark("lw_planck")
-                srcs = dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"], sfc_src_jac=buf["sfc_src_jac"])
-                if self.direct:
+                srcs = None if self.lite else dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"], sfc_src_jac=buf["sfc_src_jac"])
+                if self.lite:
+                    be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, out=buf)
+                elif self.direct:
                     be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, out=srcs)
                 else:
                     be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), out=srcs)
                 mark("lw_planck", True)
                 mark("lw_solver")
-                if self.do_broadband:
+                if self.lite:
+                    be.lw_solver_noscat_fractions(atm.top_at_1, kd, self.secants, self.weights, buf["tau"], buf, self.sfc_emis_gpt,
+                                                  flux_up=F[0], flux_dn=F[1])
+                elif self.do_broadband:
                     be._c("lw_solver_noscat", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), 1, self.secants, self.weights,
                           buf["tau"], buf["lay_src"], buf["lev_src"], self.sfc_emis_gpt, buf["sfc_src"], None, None, None,
                           BoolArg(True), F[0], F[1], BoolArg(False), None, None)

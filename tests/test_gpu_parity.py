@@ -489,3 +489,42 @@ def test_direct_gas_optics_equals_interpolation_path(kind, dt, hip_f64, hip_f32)
     a, b = res
     for k in ("tau",) + (("lay_src", "lev_src", "sfc_src") if kind == "lw" else ("ssa",)) + ("flux_up", "flux_dn"):
         assert np.array_equal(a[k], b[k]), f"{kind} {dt} {k}: direct path differs from the interpolation path"
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_planck_lite_chain(dt, top_at_1, hip_f64, hip_f32):
+    """rrx_planck_fractions + rrx_planck_sources_from_fractions reproduce rrx_planck_source_direct bit for bit (same
+    expressions), and rrx_lw_solver_noscat_fractions (sources formed inside the broadband solver, lean sqrt) matches the
+    broadband solver on the materialised sources: one-kernel form and the fallback for few columns."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    kd0 = synthetic.make_kdist("lw", **REAL_SHAPES["lw"])
+    atm0 = synthetic.make_atmosphere(200, 140, nbnd_lw=16, nbnd_sw=16, top_at_1=top_at_1, seed=19)
+    rng = np.random.default_rng(20)
+    scale = rng.uniform(0.8, 1.2, atm0.ncol)
+    atm0.p_lay = np.ascontiguousarray(atm0.p_lay * scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * scale[None, :])
+    kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
+    _, col_gas, _ = pipeline.gas_state(be, kd, atm, interpolate=False)
+    sfc_lay = pipeline._sfc_lay(atm)
+    full = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas)
+    fr = be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas)
+    lay, lev = be.planck_sources_from_fractions(kd, fr)
+    N = be.to_numpy
+    assert np.array_equal(N(lay), N(full["lay_src"])) and np.array_equal(N(lev), N(full["lev_src"]))
+    assert np.array_equal(N(fr["sfc_src"]), N(full["sfc_src"])) and np.array_equal(N(fr["sfc_src_jac"]), N(full["sfc_src_jac"]))
+    # solver: fractions form against the standard broadband form on the materialised sources
+    tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty(tuple(lay.shape)))
+    emis = be.expand_and_transpose(kd.band_lims_gpt, atm.emis_sfc, kd.ngpt)
+    sec = be.lw_secants_array(atm.ncol, kd.ngpt, 1, 4, be.asarray(pipeline.GAUSS_DS)); w = be.asarray(np.array([1.0]))
+    inc = be.asarray(rng.uniform(0, 3, (kd.ngpt, atm.ncol)))
+    tol = 1e-12 if dt == "f64" else 2e-5
+    for mg in (1, 1 << 30):                 # one-kernel form; fallback (sources rebuilt into scratch, general entry)
+        be.set_broadband_min_groups(mg)
+        try:
+            ref = be.lw_solver_noscat(top_at_1, sec, w, tau, lay, lev, emis, fr["sfc_src"], inc_flux=inc, do_broadband=True)
+            got = be.lw_solver_noscat_fractions(top_at_1, kd, sec, w, tau, fr, emis, inc_flux=inc)
+        finally:
+            be.set_broadband_min_groups(512)
+        for k in ("flux_up", "flux_dn"):
+            e = cases.rel_err(N(got[k]), N(ref[k]), floor=1e-6 if dt == "f64" else 1e-2)
+            assert e <= tol, (k, mg, e)
