@@ -54,6 +54,9 @@ int rrx_set_sw_variant(int v);
 /* column groups (8 or 16 columns x all levels) below which do_broadband falls back from the fused one-kernel form to
    per-g-point fluxes in a workspace + sum (default 512: measured break-even at C4 shapes is 256-512; 1 = always fused) */
 int rrx_set_broadband_min_groups(int n);
+/* 1 (default): the "direct" gas optics run the windowed kernel (LUT boxes staged in LDS) ahead of the gather kernel;
+   0: gather kernel only (A/B runs, tests). Like the other switches it acts on the calling host thread. */
+int rrx_set_gas_window(int on);
 
 #define RRX_DECLARE(F, SFX) \
 /* ---- Rte_solver_kernels_cuda : include_kernels_cuda/rte_solver_kernels_cuda.h:33-64 ---- */ \
@@ -215,6 +218,24 @@ int rrx_planck_fractions##SFX( \
         const int* gpoint_bands, const int* band_lims_gpt, const F* pfracin, \
         F totplnk_delta, const F* totplnk, const int* gpoint_flavor, \
         F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream); \
+/* rrx_gas_optics_lw_direct + rrx_planck_fractions in one pass over the cells: the interpolation state and the LUT windows are \
+   shared -- the LW gas optics of Gas_optics_rrtmgp_gpu in broadband mode */ \
+int rrx_gas_optics_lw_fractions##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, const int* gpoint_bands, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const F* pfracin, F totplnk_delta, const F* totplnk, \
+        F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream); \
 int rrx_planck_sources_from_fractions##SFX(int ncol, int nlay, int ngpt, const int* gpoint_bands, const F* pfrac, const F* blay, \
         const F* blev, F* lay_src, F* lev_src, void* stream); \
 int rrx_lw_solver_noscat_fractions##SFX( \

@@ -22,6 +22,7 @@ namespace rrx
         int bb_min_groups = 512;   // rrx_set_broadband_min_groups: column groups needed for the one-pass broadband form
         int sync_waves = 1;        // partner waves issue their load bursts together (env RRX_SYNC, default on)
         int go_share = 1;          // Planck shared-cell path (env RRX_GO_SHARE, default on)
+        int go_window = 1;         // windowed gas optics ahead of the gather kernel (env RRX_GO_WINDOW, default on)
     };
     Tuning& tuning();              // defined in rrx_misc.hip (thread_local)
 

@@ -10,6 +10,7 @@
 // major / minor-lower / minor-upper in three read-modify-write passes over tau.
 // The k-distribution tables are gathered through L1/L2 (neighbouring columns hit the same lines); the per-chunk
 // lists of minor contributors are built once per workgroup in LDS.
+#include <type_traits>
 #include "rrx_common.h"
 #include "rrx_hip.h"
 
@@ -251,8 +252,18 @@ tau_absorption_kernel(
         const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
         const int* __restrict__ jeta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
         const F* __restrict__ krayl,
-        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const InterpArgs<F> ia)
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const InterpArgs<F> ia,
+        const int* __restrict__ todo = nullptr, const int todo_gx = 1)
 {
+    // todo != null: this launch finishes the workgroups the windowed kernel handed back (gas_window_kernel): a 1-D grid, block b
+    // takes over workgroup todo[1+b] of the (todo_gx x .) grid; blocks beyond the count todo[0] have nothing to do
+    int blk_x = blockIdx.x, blk_y = blockIdx.y;
+    if (todo != nullptr)
+    {
+        if (int(blockIdx.x) >= todo[0]) return;
+        const int blk = todo[1 + blockIdx.x];
+        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+    }
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
@@ -287,8 +298,8 @@ tau_absorption_kernel(
     const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gflav, ngpt, mmeta, nminorlower, nminorupper);
     __syncthreads();
 
-    const int icol = blockIdx.x*blockDim.x + threadIdx.x;
-    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    const int icol = blk_x*blockDim.x + threadIdx.x;
+    const int ilay = blk_y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
 
     const size_t ncl = size_t(ncol)*nlay;
@@ -985,15 +996,22 @@ planck_fraction_kernel(
         const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
         const F totplnk_delta, const F* __restrict__ totplnk, const int* __restrict__ gpoint_flavor,
         F* __restrict__ pfrac_out, F* __restrict__ blay_out, F* __restrict__ blev_out,
-        F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac)
+        F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1)
 {
+    int blk_x = blockIdx.x, blk_y = blockIdx.y;             // todo: see tau_absorption_kernel
+    if (todo != nullptr)
+    {
+        if (int(blockIdx.x) >= todo[0]) return;
+        const int blk = todo[1 + blockIdx.x];
+        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+    }
     extern __shared__ int lds_gflav[];                       // [2][ngpt] flavor (0-based) per regime and g-point
     for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*blockDim.y)
         lds_gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
     __syncthreads();
 
-    const int icol = blockIdx.x*64 + threadIdx.x;
-    const int ilay = blockIdx.y*blockDim.y + threadIdx.y;
+    const int icol = blk_x*64 + threadIdx.x;
+    const int ilay = blk_y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
     const size_t ncl = size_t(ncol)*nlay;
     const size_t ncv = size_t(ncol)*(nlay+1);
@@ -1086,6 +1104,390 @@ planck_fraction_kernel(
     }
 }
 
+
+// =====================================================================================================================
+// Windowed gas optics. The gather kernel above is bound by the vector L1: every (cell, g-point) pulls 64 B of kmajor plus
+// 32 B per minor contributor (and Rayleigh) through a 64 B/clk pipe, although the 64 columns of a wavefront sit in a handful
+// of LUT cells. Here a workgroup (64 columns x 4 layers) stages, per 16-g-point chunk, the BOX of LUT nodes its cells use --
+// NPW pressures x NEW etas x NTW temperature pairs, 12 KB of kmajor -- in LDS with a few coalesced loads, and every cell then
+// reads its corners from LDS (256 B/clk, equal addresses broadcast): 32 x less traffic through L1. Same expressions in the
+// same order as the gather kernel, so the same bits. A workgroup whose cells do not fit the box (columns in both regimes,
+// a pressure / temperature / eta spread beyond the box, a chunk with a flavor change or more than NCW contributors) writes
+// its id to a todo list and leaves; the gather kernel is launched behind on exactly those workgroups.
+// PF: the Planck fractions ride along (planck_frac has kmajor's layout: same box, same corner weights) together with the band
+// Planck functions and the surface terms -- the whole "Planck-lite" output of planck_fraction_kernel.
+#ifndef RRX_GW_NPRE
+#define RRX_GW_NPRE 3      // minor contributors whose LDS reads go out together with the major term's
+#endif
+#ifndef RRX_GW_ABL
+#define RRX_GW_ABL 0      // ablation builds (tools/ab_gw.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop
+#endif
+constexpr int NPW = 4, NEW = 4, NTW = 3;
+constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, planck_frac
+constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
+constexpr int NCW = 6;                       // minor contributors of a chunk with a staged window
+
+template<typename F> struct PlanckArgs
+{
+    const F* pfracin; const F* tlev; const F* tsfc; int sfc_lay; int nPlanckTemp; const int* gpoint_bands;
+    F totplnk_delta; const F* totplnk; F* pfrac; F* blay; F* blev; F* sfc_src; F* sfc_src_jac;
+};
+
+template<typename F>
+size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int mode, const bool pf)
+{
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const size_t ints = size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*NCW) + size_t(2)*MM*nmax + 2*nchunk + 16;
+    const size_t pairs = size_t(GCH)*WBOX*(pf ? 2 : 1) + size_t(NCW)*GCH*MBOX + (mode == 1 ? size_t(GCH)*MBOX : 0);
+    return ((ints*sizeof(int) + 15) & ~size_t(15)) + pairs*2*sizeof(F);
+}
+
+#ifndef RRX_GW_MINW
+#define RRX_GW_MINW 3
+#endif
+template<typename F, int MODE, bool PF>
+__global__ void __launch_bounds__(256, RRX_GW_MINW)
+gas_window_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
+        const int nminorlower, const int nminorupper, const int idx_h2o,
+        const int* __restrict__ gpoint_flavor,
+        const F* __restrict__ kmajor, const F* __restrict__ kminor_lower, const F* __restrict__ kminor_upper,
+        const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
+        const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
+        const Bool* __restrict__ scale_by_complement_lower, const Bool* __restrict__ scale_by_complement_upper,
+        const int* __restrict__ idx_minor_lower, const int* __restrict__ idx_minor_upper,
+        const int* __restrict__ idx_minor_scaling_lower, const int* __restrict__ idx_minor_scaling_upper,
+        const int* __restrict__ kminor_start_lower, const int* __restrict__ kminor_start_upper,
+        const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
+        const F* __restrict__ krayl, const InterpArgs<F> ia,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const PlanckArgs<F> pa,
+        int* __restrict__ todo)
+{
+    typedef F Vec2 __attribute__((ext_vector_type(2)));
+    typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
+    extern __shared__ int lds_int[];
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const int nmax = max(nminorlower, nminorupper);
+    constexpr int LCAP = 1 + ITEM*NCW;
+    int* gflav = lds_int;                                   // [2][ngpt]
+    int* gchg = lds_int + 2*ngpt;                           // [ngpt]
+    int* lists = lds_int + 3*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
+    int* mmeta = lists + 2*nchunk*LCAP;                     // [2][nmax][MM]
+    int* cuni = mmeta + 2*MM*nmax;                          // [2][nchunk]: chunk usable by the windowed path (per regime)
+    int* red = cuni + 2*nchunk;                             // [16] workgroup reductions
+    const size_t int_bytes = ((size_t(3)*ngpt + size_t(2)*nchunk*LCAP + size_t(2)*MM*nmax + 2*nchunk + 16)*sizeof(int) + 15) & ~size_t(15);
+    Vec2* Wmaj = reinterpret_cast<Vec2*>(reinterpret_cast<char*>(lds_int) + int_bytes);     // [GCH][WBOX]
+    Vec2* Wpf  = Wmaj + GCH*WBOX;                                                           // [GCH][WBOX] (PF)
+    Vec2* Wmin = Wpf + (PF ? GCH*WBOX : 0);                                                 // [NCW][GCH][MBOX]
+    Vec2* Wray = Wmin + NCW*GCH*MBOX;                                                       // [GCH][MBOX] (MODE 1)
+
+    const int tid = threadIdx.y*64 + threadIdx.x;
+    {
+        for (int w = tid; w < 2*ngpt; w += 256) gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
+        for (int w = tid; w < ngpt; w += 256)
+            gchg[w] = (w > 0 && (gpoint_flavor[2*w] != gpoint_flavor[2*w-2] || gpoint_flavor[2*w+1] != gpoint_flavor[2*w-1])) ? 1 : 0;
+        for (int w = tid; w < nminorlower; w += 256)
+        {
+            int* m = mmeta + MM*w;
+            m[0] = idx_minor_lower[w]; m[1] = minor_scales_with_density_lower[w] ? 1 : 0;
+            m[2] = idx_minor_scaling_lower[w]; m[3] = scale_by_complement_lower[w] ? 1 : 0;
+            m[4] = minor_limits_gpt_lower[2*w]; m[5] = minor_limits_gpt_lower[2*w+1]; m[6] = kminor_start_lower[w];
+        }
+        for (int w = tid; w < nminorupper; w += 256)
+        {
+            int* m = mmeta + MM*(nmax + w);
+            m[0] = idx_minor_upper[w]; m[1] = minor_scales_with_density_upper[w] ? 1 : 0;
+            m[2] = idx_minor_scaling_upper[w]; m[3] = scale_by_complement_upper[w] ? 1 : 0;
+            m[4] = minor_limits_gpt_upper[2*w]; m[5] = minor_limits_gpt_upper[2*w+1]; m[6] = kminor_start_upper[w];
+        }
+        if (tid < 16) red[tid] = (tid >= 6) ? 0 : ((tid & 1) ? -2147483647 : 2147483647);   // 0..5: running min / max pairs; 6, 8: presence masks
+    }
+    __syncthreads();
+    // per-chunk contributor lists (ascending index = the reference's summation order) and the usability flag of the chunk:
+    // one flavor over the chunk, every contributor on that flavor, at most NCW of them
+    for (int w = tid; w < 2*nchunk; w += 256)
+    {
+        const int r = w / nchunk, c = w % nchunk;
+        const int n = r == 0 ? nminorlower : nminorupper;
+        const int c0 = c*GCH, c1 = min(c0 + GCH, ngpt);
+        int* out = lists + (r*nchunk + c)*LCAP;
+        const int fl = gflav[r*ngpt + c0];
+        bool ok = true;
+        for (int ig=c0+1; ig<c1; ++ig) ok = ok && (gflav[r*ngpt + ig] == fl);
+        int cnt = 0;
+        for (int i=0; i<n; ++i)
+        {
+            const int* m = mmeta + MM*(r*nmax + i);
+            const int lo = m[4]-1, hi = m[5];
+            if (lo < c1 && hi > c0)
+            {
+                if (cnt < NCW)
+                {
+                    int* it = out + 1 + ITEM*cnt;
+                    it[0] = i; it[1] = lo; it[2] = hi; it[3] = m[6]-1 - lo; it[4] = gflav[r*ngpt + lo];
+                    ok = ok && (it[4] == fl);
+                }
+                ++cnt;
+            }
+        }
+        out[0] = cnt;
+        cuni[w] = (ok && cnt <= NCW) ? 1 : 0;
+    }
+
+    const int icol_raw = blockIdx.x*64 + threadIdx.x;
+    const int ilay_raw = blockIdx.y*4 + threadIdx.y;
+    const bool active = icol_raw < ncol && ilay_raw < nlay;
+    const int icol = min(icol_raw, ncol-1), ilay = min(ilay_raw, nlay-1);     // inactive threads shadow a valid cell (no stores)
+    const size_t ncl = size_t(ncol)*nlay;
+    const size_t idx = icol + size_t(ilay)*ncol;
+    const F pl = play[idx], tl = tlay[idx];
+    const CellState<F> cs = cell_state<F>(ia, npres, ntemp, pl, tl);
+    const int itr = cs.itropo;
+    const int jt = cs.jt, jp = cs.jp_raw + itr;
+
+    // ---- box in temperature and pressure, one regime per workgroup
+    atomicMin(&red[0], jt); atomicMax(&red[1], jt); atomicMin(&red[2], jp); atomicMax(&red[3], jp);
+    atomicMin(&red[4], itr); atomicMax(&red[5], itr);
+    __syncthreads();
+    const int jt_lo = red[0], jp_lo = red[2];
+    bool fits = (red[1] - jt_lo < NTW) && (red[3] - jp_lo + 2 <= NPW) && (red[4] == red[5]);
+    {
+        bool all_chunks = true;
+        for (int c=0; c<nchunk; ++c) all_chunks = all_chunks && (cuni[itr*nchunk + c] != 0);
+        fits = fits && all_chunks;
+    }
+    auto hand_back = [&]()          // workgroup-uniform: the gather kernel redoes this workgroup from scratch
+    {
+        if (tid == 0) { const int k = atomicAdd(&todo[0], 1); todo[1 + k] = blockIdx.y*gridDim.x + blockIdx.x; }
+    };
+    if (!fits) { hand_back(); return; }
+
+    const int tn = ntemp*neta;
+    const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
+    constexpr unsigned SZ = sizeof(F);
+    const F cdry0 = col_gas[idx];
+    const F ch2o = col_gas[idx + size_t(idx_h2o)*ncl];
+    F ray_fac = F(0.);
+    if constexpr (MODE == 1) ray_fac = ch2o + col_dry[idx];
+    const int ti = jt - jt_lo;                                        // pair (jt-1, jt) inside the box
+    const int pi0 = jp - jp_lo;                                       // pressure node jp-1 inside the box (box starts at jp_lo-1)
+
+    auto minor_scaling = [&](const int imnr) -> F                      // gas_optics_rrtmgp_kernels.cu:505-529
+    {
+        const int* m = mmeta + MM*(itr*nmax + imnr);
+        const int imn = rfl(m[0]), swd = rfl(m[1]), ims = rfl(m[2]), sbc = rfl(m[3]);
+        F scaling = col_gas[idx + size_t(imn)*ncl];
+        const F cscal = col_gas[idx + size_t(max(ims, 0))*ncl];
+        if (swd)
+        {
+            scaling *= F(0.01) * pl / tl;
+            if (ims > 0)
+            {
+                const F vmr_fact = F(1.) / cdry0;
+                const F dry_fact = F(1.) / (F(1.) + ch2o * vmr_fact);
+                const F x = cscal * vmr_fact * dry_fact;
+                scaling *= sbc ? (F(1.) - x) : x;
+            }
+        }
+        return scaling;
+    };
+
+    // Planck-lite extras
+    [[maybe_unused]] F t_lev = F(0.), t_levp = F(0.), t_sfc = F(0.), b_sfc = F(0.), b_sfc2 = F(0.);
+    [[maybe_unused]] bool is_last = false, is_sfc = false;
+    [[maybe_unused]] int cur_bnd = -1;
+    [[maybe_unused]] const size_t ncv = size_t(ncol)*(nlay+1);
+    if constexpr (PF)
+    {
+        t_lev = pa.tlev[idx]; t_levp = pa.tlev[idx + ncol]; t_sfc = pa.tsfc[icol];
+        is_last = ilay == nlay-1; is_sfc = ilay == pa.sfc_lay-1;
+    }
+
+    int cur_flav = -1, je_lo = 1;
+    F fm[8], cm[2], fn[4]; int je[2] = {1, 1};
+    #pragma unroll
+    for (int i=0; i<8; ++i) fm[i] = F(0.);
+    cm[0] = cm[1] = F(0.); fn[0] = fn[1] = fn[2] = fn[3] = F(0.);
+    const F* kmin = itr == 0 ? kminor_lower : kminor_upper;
+    int red_slot = 6;                                                  // alternating pairs of reduction slots: 6/7, 8/9
+
+    if (RRX_GW_ABL == 1) return;
+    for (int c=0; c<nchunk; ++c)
+    {
+        const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
+        const int fl = gflav[itr*ngpt + c0];
+        if (fl != cur_flav)                                            // workgroup-uniform
+        {
+            cur_flav = fl;
+            const int gas1 = ia.flavor[2*fl], gas2 = ia.flavor[2*fl+1];
+            const F cg1 = col_gas[idx + size_t(gas1)*ncl], cg2 = col_gas[idx + size_t(gas2)*ncl];
+            #pragma unroll
+            for (int itemp=0; itemp<2; ++itemp)
+            {
+                F fmi[2], fma[4];
+                flavor_state<F>(ia, cs, neta, itemp, gas1, gas2, cg1, cg2, cm[itemp], je[itemp], fmi, fma);
+                fn[2*itemp] = fmi[0]; fn[2*itemp+1] = fmi[1];
+                fm[4*itemp] = fma[0]; fm[4*itemp+1] = fma[1]; fm[4*itemp+2] = fma[2]; fm[4*itemp+3] = fma[3];
+            }
+            // eta box of this flavor over the workgroup: presence mask of the eta indices in use (bit j = some cell has je == j),
+            // built per wavefront from ballots (scalar work) and merged with one LDS atomic per wavefront
+            unsigned present = 0u;
+            for (int j=1; j<neta; ++j)
+                if (__ballot(je[0] == j || je[1] == j) != 0ull) present |= (1u << j);
+            if (threadIdx.x == 0) atomicOr(reinterpret_cast<unsigned*>(&red[red_slot]), present);
+            __syncthreads();
+            const unsigned all_present = reinterpret_cast<unsigned*>(red)[red_slot];
+            je_lo = __ffs(int(all_present)) - 1;
+            const int je_hi = 31 - __clz(int(all_present));
+            red_slot = (red_slot == 6) ? 8 : 6;
+            if (tid == 0) red[red_slot] = 0;                            // visible after the next barrier
+            if (je_hi - je_lo + 2 > NEW) { hand_back(); return; }
+        }
+        // (the regime is the same in every lane here: readfirstlane moves the chunk's list into scalar registers, so that the
+        //  contributor conditions of the g-point loop are scalar branches instead of exec-mask sequences)
+        const int itr_s = rfl(itr);
+        const int n = rfl(lists[(itr_s*nchunk + c)*LCAP]);
+        const int* items = lists + (itr_s*nchunk + c)*LCAP + 1;
+
+        __syncthreads();                        // the previous chunk's readers are done with the windows
+        // ---- stage the boxes: pairs (T, T+1) are adjacent words of the tables (temperature is their fastest dimension)
+        if (RRX_GW_ABL != 2)
+        {
+            const int nmaj = ng*WBOX;
+            for (int q = tid; q < nmaj; q += 256)
+            {
+                const int gi = q / WBOX, r = q % WBOX;
+                const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
+                const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
+                const size_t off = size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn;
+                Wmaj[gi*WBOX + r] = *reinterpret_cast<const Vec2u*>(kmajor + off);
+                if constexpr (PF) Wpf[gi*WBOX + r] = *reinterpret_cast<const Vec2u*>(pa.pfracin + off);
+            }
+            const int nmin = ng*MBOX;
+            for (int i=0; i<n; ++i)
+            {
+                const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                for (int q = tid; q < nmin; q += 256)
+                {
+                    const int gi = q / MBOX, r = q % MBOX;
+                    const int e = r / NTW, t = r % NTW;
+                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1);
+                    const int kg = min(max(c0 + gi, lo), hi-1);                  // clamped: always a valid table row
+                    Wmin[(i*GCH + gi)*MBOX + r] = *reinterpret_cast<const Vec2u*>(kmin + size_t(kg + koff)*tn + it_ + ie*ntemp);
+                }
+            }
+            if constexpr (MODE == 1)
+            {
+                const F* kr = krayl + size_t(itr)*tn*ngpt;
+                for (int q = tid; q < nmin; q += 256)
+                {
+                    const int gi = q / MBOX, r = q % MBOX;
+                    const int e = r / NTW, t = r % NTW;
+                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1);
+                    Wray[gi*MBOX + r] = *reinterpret_cast<const Vec2u*>(kr + size_t(c0 + gi)*tn + it_ + ie*ntemp);
+                }
+            }
+        }
+        // per-cell scalings of this chunk's contributors (registers; independent of the staging above)
+        F sc[NCW]; int slo[NCW], shi[NCW];
+        #pragma unroll
+        for (int i=0; i<NCW; ++i)
+        {
+            sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
+            if (i < n) { sc[i] = minor_scaling(rfl(items[ITEM*i])); slo[i] = rfl(items[ITEM*i+1]); shi[i] = rfl(items[ITEM*i+2]); }
+        }
+        __syncthreads();
+
+        // ---- the cell's corners inside the boxes
+        const int e0 = je[0] - je_lo, e1 = je[1] - je_lo;               // eta node je-1 sits at box index je - je_lo
+        const int m00 = (pi0*NEW + e0)*NTW + ti, m10 = (pi0*NEW + e1)*NTW + ti;      // kmajor: pressure node jp-1, eta node je-1
+        const int q0 = e0*NTW + ti, q1 = e1*NTW + ti;                               // kminor / krayl
+        const bool wave_same_eta = !__any(je[0] != je[1]);
+
+        // ---- the chunk's g-points, one per iteration (measured alternatives, all slower on MI355X: batches of 2-8 g-points
+        // with their LDS reads issued together -- the registers cost the third wave per SIMD --, contributor reads preloaded
+        // next to the major term's, per-contributor sweeps over the chunk, straight-line specialisations per contributor count)
+        if (RRX_GW_ABL != 3)
+        for (int gi=0; gi<ng; ++gi)
+        {
+            const int ig = c0 + gi;
+            const Vec2* wm = Wmaj + gi*WBOX;
+            // corners: lower temperature node (jt-1) = .x of the pair, upper (jt) = .y; the upper node uses its own eta index
+            const Vec2 a0 = wm[m00], a1 = wm[m00 + NTW], a2 = wm[m00 + NEW*NTW], a3 = wm[m00 + NEW*NTW + NTW];
+            F k4 = a0.y, k5 = a1.y, k6 = a2.y, k7 = a3.y;
+            if (!wave_same_eta) { k4 = wm[m10].y; k5 = wm[m10 + NTW].y; k6 = wm[m10 + NEW*NTW].y; k7 = wm[m10 + NEW*NTW + NTW].y; }
+            F t = cm[0] * (fm[0]*a0.x + fm[1]*a1.x + fm[2]*a2.x + fm[3]*a3.x)
+                + cm[1] * (fm[4]*k4 + fm[5]*k5 + fm[6]*k6 + fm[7]*k7);
+            #pragma unroll
+            for (int i=0; i<NCW; ++i)                                   // ascending contributor index: the reference's order
+            {
+                if (i < n && ig >= slo[i] && ig < shi[i])
+                {
+                    const Vec2* wn = Wmin + (i*GCH + gi)*MBOX;
+                    const Vec2 c0v = wn[q0], c1v = wn[q0 + NTW];
+                    F m2 = c0v.y, m3 = c1v.y;
+                    if (!wave_same_eta) { m2 = wn[q1].y; m3 = wn[q1 + NTW].y; }
+                    const F kk = fn[0]*c0v.x + fn[1]*c1v.x + fn[2]*m2 + fn[3]*m3;
+                    t = t + kk * sc[i];
+                }
+            }
+            const size_t o = idx + size_t(ig)*ncl;
+            if constexpr (MODE == 2)
+            {
+                if (active) tau[o] = t;
+            }
+            else
+            {
+                const Vec2* wr = Wray + gi*MBOX;
+                const Vec2 r0 = wr[q0], r1 = wr[q0 + NTW];
+                F r2 = r0.y, r3 = r1.y;
+                if (!wave_same_eta) { r2 = wr[q1].y; r3 = wr[q1 + NTW].y; }
+                const F ray = ray_fac * (fn[0]*r0.x + fn[1]*r1.x + fn[2]*r2 + fn[3]*r3);
+                const F tt = t + ray;
+                if (active)
+                {
+                    tau[o] = tt;
+                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
+                    if (g != nullptr) g[o] = F(0.);
+                }
+            }
+            if constexpr (PF)
+            {
+                const Vec2* wp = Wpf + gi*WBOX;
+                const Vec2 p0 = wp[m00], p1 = wp[m00 + NTW], p2 = wp[m00 + NEW*NTW], p3 = wp[m00 + NEW*NTW + NTW];
+                F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
+                if (!wave_same_eta) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
+                const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
+                const int ibnd = pa.gpoint_bands[ig] - 1;
+                if (ibnd != cur_bnd)
+                {
+                    cur_bnd = ibnd;
+                    const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
+                    const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                    const F bv = interp1d(t_lev, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                    if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
+                    if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(t_levp, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                    if (is_sfc)
+                    {
+                        b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                    }
+                }
+                if (active)
+                {
+                    pa.pfrac[o] = pfrac;
+                    if (is_sfc)
+                    {
+                        pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
+                        pa.sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
+                    }
+                }
+            }
+        }
+    }
+    (void)SZ;
+}
+
 template<typename F>
 __global__ void reorder123x321_kernel(const int ni, const int nj, const int nk, const F* __restrict__ in, F* __restrict__ out)
 {
@@ -1117,6 +1519,70 @@ template<typename F> size_t planck_lds_bytes(const int ngpt)
     return size_t(GCH)*(PL+1)*64*sizeof(F) + size_t((2*ngpt + 3) & ~3)*sizeof(int) + size_t(PL)*2*4*GCH*2*sizeof(F);
 }
 
+// LW gas optics + Planck-lite in one pass: windowed kernel with the Planck fractions riding along; the workgroups it hands
+// back are finished by the gather kernel (tau) and planck_fraction_kernel (fractions, band Planck functions, surface terms)
+template<typename F>
+int gas_optics_lw_fractions_impl(
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp,
+        int nminorlower, int nminorupper, int idx_h2o,
+        const int* gpoint_flavor, const int* gpoint_bands,
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper,
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+        const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+        const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+        const int* idx_minor_lower, const int* idx_minor_upper,
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper,
+        const int* kminor_start_lower, const int* kminor_start_upper,
+        const InterpArgs<F> ia, const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas,
+        const F* pfracin, F totplnk_delta, const F* totplnk,
+        F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream)
+{
+    RRX_TRY
+    (void)nband; (void)ngas; (void)nflav;
+    if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const int nmax = std::max(nminorlower, nminorupper);
+    const size_t lds = (size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*nmax) + size_t(2)*MM*nmax)*sizeof(int);
+    if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
+    const dim3 block(64, 4);
+    const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
+    const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, 2, true);
+    const bool windowed = tuning().go_window && wlds <= 64*1024;
+    StreamScratch scratch(st);
+    const int nblk = int(grid.x)*int(grid.y);
+    int* todo = nullptr;
+    if (windowed)
+    {
+        todo = scratch.get<int>(size_t(1) + nblk);
+        if (hipMemsetAsync(todo, 0, sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+        const PlanckArgs<F> pa{pfracin, tlev, tsfc, sfc_lay, nPlanckTemp, gpoint_bands, totplnk_delta, totplnk, pfrac, blay, blev, sfc_src, sfc_src_jac};
+        gas_window_kernel<F,2,true><<<grid, block, wlds, st>>>(
+                ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
+                kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                minor_scales_with_density_lower, minor_scales_with_density_upper,
+                scale_by_complement_lower, scale_by_complement_upper,
+                idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia,
+                tau, (F*)nullptr, (F*)nullptr, pa, todo);
+    }
+    const dim3 g2 = windowed ? dim3(nblk) : grid;
+    tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(
+            ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+            minor_scales_with_density_lower, minor_scales_with_density_upper,
+            scale_by_complement_lower, scale_by_complement_upper,
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+            kminor_start_lower, kminor_start_upper,
+            (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr,
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr,
+            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x));
+    planck_fraction_kernel<F><<<g2, block, size_t(2)*ngpt*sizeof(int), st>>>(
+            ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin,
+            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x));
+    RRX_CATCH("rrx_gas_optics_lw_fractions")
+}
+
 template<typename F, int MODE, bool DIRECT = false>
 int tau_absorption_impl(
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp,
@@ -1143,6 +1609,37 @@ int tau_absorption_impl(
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
+    if constexpr (DIRECT && MODE != 0)
+    {
+        // windowed kernel first; the gather kernel then finishes the workgroups it handed back (usually none)
+        const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, MODE, false);
+        if (tuning().go_window && wlds <= 64*1024)
+        {
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            StreamScratch scratch(st);
+            const int nblk = int(grid.x)*int(grid.y);
+            int* todo = scratch.get<int>(size_t(1) + nblk);
+            if (hipMemsetAsync(todo, 0, sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+            gas_window_kernel<F,MODE,false><<<grid, block, wlds, st>>>(
+                    ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
+                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                    minor_scales_with_density_lower, minor_scales_with_density_upper,
+                    scale_by_complement_lower, scale_by_complement_upper,
+                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                    kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g,
+                    PlanckArgs<F>(), todo);
+            tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk), block, lds, st>>>(
+                    ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
+                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                    minor_scales_with_density_lower, minor_scales_with_density_upper,
+                    scale_by_complement_lower, scale_by_complement_upper,
+                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                    kminor_start_lower, kminor_start_upper,
+                    tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
+                    tau, ssa, g, ia, todo, int(grid.x));
+            return check_launch(name);
+        }
+    }
     tau_absorption_kernel<F,MODE,DIRECT><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
             kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
@@ -1314,6 +1811,31 @@ int rrx_planck_source_direct##SFX( \
             (const int*)nullptr, (const int*)nullptr, gpoint_bands, pfracin, temp_ref_min, totplnk_delta, totplnk, gpoint_flavor, \
             sfc_src, lay_src, lev_src, sfc_src_jac, tuning().go_share, play, col_gas, ia); \
     RRX_CATCH("rrx_planck_source_direct") \
+} \
+int rrx_gas_optics_lw_fractions##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, const int* gpoint_bands, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const F* pfracin, F totplnk_delta, const F* totplnk, \
+        F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream) \
+{ \
+    (void)nminorklower; (void)nminorkupper; (void)band_lims_gpt; \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    return gas_optics_lw_fractions_impl<F>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, nPlanckTemp, nminorlower, nminorupper, idx_h2o, \
+            gpoint_flavor, gpoint_bands, kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            ia, play, tlay, tlev, tsfc, sfc_lay, col_gas, pfracin, totplnk_delta, totplnk, tau, pfrac, blay, blev, sfc_src, sfc_src_jac, stream); \
 } \
 int rrx_planck_fractions##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \

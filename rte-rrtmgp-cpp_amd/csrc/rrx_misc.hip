@@ -19,6 +19,7 @@ namespace rrx
             Tuning d;
             if (const char* e = getenv("RRX_SYNC")) d.sync_waves = atoi(e);
             if (const char* e = getenv("RRX_GO_SHARE")) d.go_share = atoi(e);
+            if (const char* e = getenv("RRX_GO_WINDOW")) d.go_window = atoi(e);
             return d;
         }();
         return t;
@@ -318,6 +319,7 @@ __global__ void fill_kernel(const size_t n, const F v, F* __restrict__ a)
 extern "C"
 {
 const char* rrx_last_error(void) { return rrx::g_last_error.c_str(); }
+int rrx_set_gas_window(int on) { rrx::tuning().go_window = on; return 0; }
 
 #define RRX_HIP_OK(call, name) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { \
     rrx::set_error(std::string(name) + ": " + hipGetErrorString(e_)); return 2; } } while (0)

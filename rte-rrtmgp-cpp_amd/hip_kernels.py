@@ -236,6 +236,18 @@ class HipKernels:
                 out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"])
         return out
 
+    def gas_optics_lw_fractions(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, tau, out=None):
+        """tau and the Planck-lite outputs in one pass (rrx_gas_optics_lw_fractions)"""
+        nlay, ncol = tlay.shape
+        if out is None:
+            out = dict(pfrac=self.empty((kd.ngpt, nlay, ncol)), blay=self.empty((kd.nbnd, nlay, ncol)),
+                       blev=self.empty((kd.nbnd, nlay+1, ncol)), sfc_src=self.empty((kd.ngpt, ncol)), sfc_src_jac=self.empty((kd.ngpt, ncol)))
+        a = self._minor_args(kd, play)
+        self._c("gas_optics_lw_fractions", *a[:9], kd.nPlanckTemp, *a[9:16], kd.gpoint_bands, *a[16:], *self._direct_args(kd),
+                play, tlay, tlev, tsfc, sfc_lay, col_gas, kd.planck_frac, float(kd.totplnk_delta), kd.totplnk,
+                tau, out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"])
+        return out
+
     def planck_sources_from_fractions(self, kd, fr, lay_src=None, lev_src=None):
         ngpt, nlay, ncol = fr["pfrac"].shape
         lay_src = self.empty((ngpt, nlay, ncol)) if lay_src is None else lay_src

@@ -74,13 +74,14 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
 
     fr = None
     if direct:          # product default: interpolation recomputed inside the two consumers, no intermediate arrays
-        tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
-        if lite:
-            fr = be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
+        if lite:        # tau and the Planck-lite outputs in one pass over the cells
+            tau = be.empty((ngpt, nlay, ncol))
+            fr = be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, tau)
             src = dict(sfc_src=fr["sfc_src"], sfc_src_jac=fr["sfc_src_jac"], lay_src=None, lev_src=None)
             if keep:
                 src["lay_src"], src["lev_src"] = be.planck_sources_from_fractions(kd, fr)
         else:
+            tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
             src = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
     else:
         if hasattr(be, "compute_tau_absorption_set"):
@@ -252,7 +253,9 @@ class ResidentSolver:
             col_gas = be.fill_gases(kd, atm.vmr, col_dry)
             it = None if self.direct else be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
             if kind == "lw":
-                if self.direct:
+                if self.lite:
+                    be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, buf["tau"], out=buf)
+                elif self.direct:
                     be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
                 else:
                     be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
@@ -260,7 +263,7 @@ class ResidentSolver:
                 mark("lw_planck")
                 srcs = None if self.lite else dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"], sfc_src_jac=buf["sfc_src_jac"])
                 if self.lite:
-                    be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, out=buf)
+                    pass                                   # the fractions came with the optical depths
                 elif self.direct:
                     be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, out=srcs)
                 else:

@@ -528,3 +528,44 @@ def test_planck_lite_chain(dt, top_at_1, hip_f64, hip_f32):
         for k in ("flux_up", "flux_dn"):
             e = cases.rel_err(N(got[k]), N(ref[k]), floor=1e-6 if dt == "f64" else 1e-2)
             assert e <= tol, (k, mg, e)
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_windowed_gas_optics_and_fused_fractions(dt, hip_f64, hip_f32):
+    """The windowed kernels (LUT boxes staged in LDS) against the gather kernels they replace, on an atmosphere where most
+    workgroups take the windowed path and some are handed back (tropopause rows, a few columns far off in pressure): optical
+    depths and single-scattering albedo bit for bit (same expressions, same order); rrx_gas_optics_lw_fractions = tau +
+    Planck-lite outputs in one pass, bit for bit against rrx_gas_optics_lw_direct + rrx_planck_fractions."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    N = be.to_numpy
+    rng = np.random.default_rng(31)
+    for kind in ("lw", "sw"):
+        kd0 = synthetic.make_kdist(kind, **REAL_SHAPES[kind])
+        nb = REAL_SHAPES[kind]["nbnd"]
+        atm0 = synthetic.make_atmosphere(384, 140, nbnd_lw=nb, nbnd_sw=nb, seed=29)
+        scale = np.ones(atm0.ncol); scale[rng.integers(0, atm0.ncol, 6)] = rng.uniform(0.5, 1.5, 6)     # a few outliers
+        atm0.p_lay = np.ascontiguousarray(atm0.p_lay * scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * scale[None, :])
+        kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
+        col_dry, col_gas, _ = pipeline.gas_state(be, kd, atm, interpolate=False)
+        shape = (kd.ngpt, atm.nlay, atm.ncol)
+        outs = []
+        for window in (1, 0):
+            be.lib.call("rrx_set_gas_window", window)
+            if kind == "lw":
+                tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty(shape))
+                outs.append([N(tau)])
+            else:
+                tau, ssa, g = be.empty(shape), be.empty(shape), be.empty(shape)
+                be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
+                outs.append([N(tau), N(ssa), N(g)])
+        be.lib.call("rrx_set_gas_window", 1)
+        for a_, b_ in zip(*outs):
+            assert np.array_equal(a_, b_), f"{kind} {dt}: windowed kernel differs from the gather kernel"
+        if kind == "lw":
+            sfc_lay = pipeline._sfc_lay(atm)
+            fr_ref = be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas)
+            tau2 = be.empty(shape)
+            fr = be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas, tau2)
+            assert np.array_equal(N(tau2), outs[0][0])
+            for k in ("pfrac", "blay", "blev", "sfc_src", "sfc_src_jac"):
+                assert np.array_equal(N(fr[k]), N(fr_ref[k])), k
