@@ -189,12 +189,13 @@ class Gas_optics_rrtmgp_gpu : public Gas_optics_gpu
 
         void set_solar_variability(const Float mg_index, const Float sb_index);
 
-        struct Interp_state;   // jtemp, jpress, tropo, jeta, fmajor, fminor, col_mix, col_gas of one call
-        void compute_gas_taus(
-                const int ncol, const int nlay,
-                const Array_gpu<Float,2>& play, const Array_gpu<Float,2>& tlay,
-                const Gas_concs_gpu& gas_desc,
-                std::unique_ptr<Optical_props_arry_gpu>& optical_props,
-                const Array_gpu<Float,2>& col_dry, Interp_state& st);
+        void fill_col_gas(const int ncol, const int nlay, const Gas_concs_gpu& gas_desc, const Array_gpu<Float,2>& col_dry,
+                          Array_gpu<Float,3>& col_gas);
+        int vertical_ordering = -1;
+    public:
+        // Host-model coupling: -1 (default) = detect the vertical ordering from play with the reference's synchronous
+        // one-element read-back (src_cuda/Gas_optics_rrtmgp.cu:1190); 0 = surface first, 1 = top of atmosphere first:
+        // no read-back, gas_optics() is then fully asynchronous on the calling thread's stream (rrx_host::set_stream).
+        void set_vertical_ordering(const int top_at_1) { vertical_ordering = top_at_1; }
 };
 #endif

@@ -251,6 +251,9 @@ int rrx_delta_scale_2str_k##SFX(int ncol, int nlay, int ngpt, F* tau_inout, F* s
 /* ---- Fluxes_kernels_cuda : include_kernels_cuda/fluxes_kernels_cuda.h:33-51 ---- */ \
 int rrx_sum_broadband##SFX(int ncol, int nlev, int ngpt, const F* gpt_flux, F* flux, void* stream); \
 int rrx_net_broadband_precalc##SFX(int ncol, int nlev, const F* flux_dn, const F* flux_up, F* flux_net, void* stream); \
+/* host-model coupling (no counterpart in the reference library): layer heating rate [K/s] from the net (down - up) \
+   broadband flux flux_net(ncol,nlay+1) and the level pressures plev(ncol,nlay+1): -(g/cp) * dF_net/dp, either vertical ordering */ \
+int rrx_heating_rate##SFX(int ncol, int nlay, F g_over_cp, const F* flux_net, const F* plev, F* heating_rate, void* stream); \
 /* by-band: Fortran semantics (src_kernels/mo_fluxes_byband_kernels.F90:22-71; the CUDA text is buggy): \
    band_lims is (2,nbnd), 1-based inclusive, gpt_flux is the SPECTRAL (ncol,nlev,ngpt) array */ \
 int rrx_sum_byband##SFX(int ncol, int nlev, int ngpt, int nbnd, const int* band_lims, const F* gpt_flux, F* bnd_flux, void* stream); \

@@ -25,6 +25,10 @@
 #include "Rte_lw.h"
 #include "Rte_sw.h"
 
+// Layer heating rates [K/s] from net (down - up) broadband fluxes and level pressures, on the device:
+// -(g/cp) dF_net/dp with g = 9.80665 m s-2, cp = 1004.64 J kg-1 K-1 (dry air). flux_net, p_lev: (ncol, nlay+1); out: (ncol, nlay).
+void compute_heating_rate(const Array_gpu<Float,2>& flux_net, const Array_gpu<Float,2>& p_lev, Array_gpu<Float,2>& heating_rate);
+
 class Radiation_solver_longwave
 {
     public:
@@ -57,11 +61,17 @@ class Radiation_solver_longwave
 
         void set_column_block(const int n) { n_col_block = n; }
         void set_broadband_solvers(const bool b) { broadband_solvers = b; }
+        // Host-model coupling: the solver object is persistent -- k-distribution and LUTs stay on the device, block
+        // workspaces are cached across calls -- and with the vertical ordering stated (0 = surface first, 1 = top first; -1 =
+        // detect with the reference's synchronous read-backs) solve_gpu() enqueues everything on the calling thread's stream
+        // (rrx_host::set_stream) without synchronising, so a host model can overlap it with its own work.
+        void set_vertical_ordering(const int top_at_1) { vertical_ordering = top_at_1; kdist_gpu->set_vertical_ordering(top_at_1); }
 
     private:
         std::unique_ptr<Gas_optics_rrtmgp_gpu> kdist_gpu;
         std::unique_ptr<Cloud_optics_gpu> cloud_optics_gpu;
         Rte_lw_gpu rte_lw;
+        int vertical_ordering = -1;
         int n_col_block = 16384;
         bool broadband_solvers = true;
 
@@ -113,11 +123,13 @@ class Radiation_solver_shortwave
 
         void set_column_block(const int n) { n_col_block = n; }
         void set_broadband_solvers(const bool b) { broadband_solvers = b; }
+        void set_vertical_ordering(const int top_at_1) { vertical_ordering = top_at_1; kdist_gpu->set_vertical_ordering(top_at_1); }
 
     private:
         std::unique_ptr<Gas_optics_rrtmgp_gpu> kdist_gpu;
         std::unique_ptr<Cloud_optics_gpu> cloud_optics_gpu;
         Rte_sw_gpu rte_sw;
+        int vertical_ordering = -1;
         int n_col_block = 16384;
         bool broadband_solvers = true;
 

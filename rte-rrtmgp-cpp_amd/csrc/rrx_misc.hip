@@ -43,6 +43,19 @@ using namespace rrx;
 inline int grid1d(const size_t n) { return int(std::min<size_t>((n + 255)/256, 256*16)); }
 #define RRX_GRID_STRIDE(i, n) for (size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x; i < (n); i += size_t(gridDim.x)*blockDim.x)
 
+// heating rate of a layer from the net (down - up) broadband flux at its two levels: dT/dt = -(g/cp) d(F_dn - F_up)/dp [K/s]
+// (no counterpart in the reference library: its host model MicroHH differentiates the fluxes itself)
+template<typename F>
+__global__ void heating_rate_kernel(const size_t n, const int ncol, const F g_over_cp, const F* __restrict__ flux_net,
+                                    const F* __restrict__ plev, F* __restrict__ hr)
+{
+    RRX_GRID_STRIDE(i, n)
+    {
+        const F dp = plev[i + ncol] - plev[i];
+        hr[i] = -g_over_cp * (flux_net[i + ncol] - flux_net[i]) / dp;
+    }
+}
+
 // ---- optical props: /root/reference/src_kernels_cuda/optical_props_kernels.cu:31-161 ----
 template<typename F>
 __global__ void inc_1scl_kernel(const size_t n, F* __restrict__ tau1, const F* __restrict__ tau2)
@@ -375,6 +388,9 @@ int rrx_sum_broadband##SFX(int ncol, int nlev, int ngpt, const F* gpt_flux, F* f
 int rrx_net_broadband_precalc##SFX(int ncol, int nlev, const F* flux_dn, const F* flux_up, F* flux_net, void* stream) \
 { RRX_TRY const size_t n = size_t(ncol)*nlev; \
   net_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, flux_dn, flux_up, flux_net); RRX_CATCH("rrx_net_broadband_precalc") } \
+int rrx_heating_rate##SFX(int ncol, int nlay, F g_over_cp, const F* flux_net, const F* plev, F* heating_rate, void* stream) \
+{ RRX_TRY const size_t n = size_t(ncol)*nlay; \
+  heating_rate_kernel<F><<<grid1d(n), 256, 0, ST>>>(n, ncol, g_over_cp, flux_net, plev, heating_rate); RRX_CATCH("rrx_heating_rate") } \
 int rrx_sum_byband##SFX(int ncol, int nlev, int ngpt, int nbnd, const int* band_lims, const F* gpt_flux, F* bnd_flux, void* stream) \
 { RRX_TRY (void)ngpt; const size_t n = size_t(ncol)*nlev; \
   byband_kernel<F,false><<<dim3(std::min(grid1d(n), 1024), nbnd), 256, 0, ST>>>(n, band_lims, gpt_flux, (const F*)nullptr, bnd_flux); RRX_CATCH("rrx_sum_byband") } \

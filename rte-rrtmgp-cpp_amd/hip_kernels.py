@@ -344,6 +344,12 @@ class HipKernels:
         self._c("net_broadband_precalc", ncol, nlev, flux_dn, flux_up, out)
         return out
 
+    def heating_rate(self, flux_net, plev, g_over_cp=9.80665/1004.64):
+        nlev, ncol = flux_net.shape
+        out = self.empty((nlev-1, ncol))
+        self._c("heating_rate", ncol, nlev-1, float(g_over_cp), flux_net, plev, out)
+        return out
+
     def sum_byband(self, gpt_flux, band_lims):
         ngpt, nlev, ncol = gpt_flux.shape
         nbnd = band_lims.shape[0]

@@ -98,16 +98,7 @@ namespace
 }
 
 
-struct Gas_optics_rrtmgp_gpu::Interp_state
-{
-    Array_gpu<int,2> jtemp, jpress;
-    Array_gpu<Bool,2> tropo;
-    Array_gpu<Float,6> fmajor;
-    Array_gpu<int,4> jeta;
-    Array_gpu<Float,3> col_gas;
-    Array_gpu<Float,4> col_mix;
-    Array_gpu<Float,5> fminor;
-};
+
 
 
 // Constructor of longwave variant.
@@ -400,70 +391,34 @@ void Gas_optics_rrtmgp_gpu::get_col_dry(Array_gpu<Float,2>& col_dry, const Array
 }
 
 
-void Gas_optics_rrtmgp_gpu::compute_gas_taus(
-        const int ncol, const int nlay,
-        const Array_gpu<Float,2>& play, const Array_gpu<Float,2>& tlay,
-        const Gas_concs_gpu& gas_desc,
-        std::unique_ptr<Optical_props_arry_gpu>& optical_props,
-        const Array_gpu<Float,2>& col_dry, Interp_state& st)
+// col_gas(ncol,nlay,0:ngas): slot 0 = col_dry, slot i = vmr_i*col_dry (src_cuda/Gas_optics_rrtmgp.cu:392-422,1023-1028)
+void Gas_optics_rrtmgp_gpu::fill_col_gas(
+        const int ncol, const int nlay, const Gas_concs_gpu& gas_desc, const Array_gpu<Float,2>& col_dry, Array_gpu<Float,3>& col_gas)
 {
-    const int ngpt = this->get_ngpt();
-    const int nband = this->get_nband();
     const int ngas = this->gas_names.dim(1);
-    const int nflav = this->get_nflav();
-
-    st.jtemp.set_dims({ncol, nlay}); st.jpress.set_dims({ncol, nlay}); st.tropo.set_dims({ncol, nlay});
-    st.fmajor.set_dims({2, 2, 2, ncol, nlay, nflav}); st.jeta.set_dims({2, ncol, nlay, nflav});
-    st.col_gas.set_dims({ncol, nlay, ngas+1}); st.col_mix.set_dims({2, ncol, nlay, nflav}); st.fminor.set_dims({2, 2, ncol, nlay, nflav});
+    col_gas.set_dims({ncol, nlay, ngas+1});
     Array_gpu<Float,3> vmr({ncol, nlay, ngas});
-
     for (int igas=0; igas<=ngas; ++igas)
     {
         const Array_gpu<Float,2>& vmr_2d = gas_desc.get_vmr(this->gas_names({igas > 0 ? igas : 1}));
-        RRX_CALL(rrx_fill_gases, ncol, nlay, vmr_2d.dim(1), vmr_2d.dim(2), ngas, igas, vmr.ptr(), vmr_2d.ptr(), st.col_gas.ptr(), col_dry.ptr());
-    }
-
-    Gas_optics_rrtmgp_kernels_cuda::interpolation(
-            ncol, nlay, ngas, nflav, neta, npres, ntemp,
-            flavor_gpu.ptr(), press_ref_log_gpu.ptr(), temp_ref_gpu.ptr(),
-            press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log,
-            vmr_ref_gpu.ptr(), play.ptr(), tlay.ptr(), st.col_gas.ptr(),
-            st.jtemp.ptr(), st.fmajor.ptr(), st.fminor.ptr(), st.col_mix.ptr(), st.tropo.ptr(), st.jeta.ptr(), st.jpress.ptr());
-
-    const int* band_lims = this->get_band_lims_gpoint_gpu().ptr();
-    if (has_rayleigh)
-    {
-        // absorption + Rayleigh + combine in one pass over the output (same arithmetic as the three reference launchers)
-        Gas_optics_rrtmgp_kernels_cuda::gas_optics_sw_fused(
-                ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp,
-                nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o,
-                gpoint_flavor_gpu.ptr(), band_lims, kmajor_gpu.ptr(), kminor_lower_gpu.ptr(), kminor_upper_gpu.ptr(),
-                minor_limits_gpt_lower_gpu.ptr(), minor_limits_gpt_upper_gpu.ptr(),
-                minor_scales_with_density_lower_gpu.ptr(), minor_scales_with_density_upper_gpu.ptr(),
-                scale_by_complement_lower_gpu.ptr(), scale_by_complement_upper_gpu.ptr(),
-                idx_minor_lower_gpu.ptr(), idx_minor_upper_gpu.ptr(), idx_minor_scaling_lower_gpu.ptr(), idx_minor_scaling_upper_gpu.ptr(),
-                kminor_start_lower_gpu.ptr(), kminor_start_upper_gpu.ptr(),
-                st.tropo.ptr(), st.col_mix.ptr(), st.fmajor.ptr(), st.fminor.ptr(), play.ptr(), tlay.ptr(), st.col_gas.ptr(), col_dry.ptr(),
-                st.jeta.ptr(), st.jtemp.ptr(), st.jpress.ptr(), krayl_gpu.ptr(),
-                optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), static_cast<Float*>(nullptr));
-        optical_props->set_g_zero();          // g == 0: not written; materialised on the first get_g() (clouds, output)
-    }
-    else
-    {
-        // tau = major + minor in one pass (the reference zero-fills tau and adds onto it: same values)
-        Gas_optics_rrtmgp_kernels_cuda::compute_tau_absorption_set(
-                ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp,
-                nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o,
-                gpoint_flavor_gpu.ptr(), band_lims, kmajor_gpu.ptr(), kminor_lower_gpu.ptr(), kminor_upper_gpu.ptr(),
-                minor_limits_gpt_lower_gpu.ptr(), minor_limits_gpt_upper_gpu.ptr(),
-                minor_scales_with_density_lower_gpu.ptr(), minor_scales_with_density_upper_gpu.ptr(),
-                scale_by_complement_lower_gpu.ptr(), scale_by_complement_upper_gpu.ptr(),
-                idx_minor_lower_gpu.ptr(), idx_minor_upper_gpu.ptr(), idx_minor_scaling_lower_gpu.ptr(), idx_minor_scaling_upper_gpu.ptr(),
-                kminor_start_lower_gpu.ptr(), kminor_start_upper_gpu.ptr(),
-                st.tropo.ptr(), st.col_mix.ptr(), st.fmajor.ptr(), st.fminor.ptr(), play.ptr(), tlay.ptr(), st.col_gas.ptr(),
-                st.jeta.ptr(), st.jtemp.ptr(), st.jpress.ptr(), optical_props->get_tau().ptr());
+        RRX_CALL(rrx_fill_gases, ncol, nlay, vmr_2d.dim(1), vmr_2d.dim(2), ngas, igas, vmr.ptr(), vmr_2d.ptr(), col_gas.ptr(), col_dry.ptr());
     }
 }
+
+// The "direct" entry points compute the interpolation state (interpolation_kernel of the reference) inside its consumers:
+// same expressions and bits as interpolation -> compute_tau_absorption -> ..., without the seven intermediate arrays.
+#define RRX_MINOR_ARGS \
+        ncol, nlay, this->get_nband(), this->get_ngpt(), ngas, this->get_nflav(), neta, npres, ntemp, \
+        nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, \
+        gpoint_flavor_gpu.ptr(), this->get_band_lims_gpoint_gpu().ptr(), kmajor_gpu.ptr(), kminor_lower_gpu.ptr(), kminor_upper_gpu.ptr(), \
+        minor_limits_gpt_lower_gpu.ptr(), minor_limits_gpt_upper_gpu.ptr(), \
+        minor_scales_with_density_lower_gpu.ptr(), minor_scales_with_density_upper_gpu.ptr(), \
+        scale_by_complement_lower_gpu.ptr(), scale_by_complement_upper_gpu.ptr(), \
+        idx_minor_lower_gpu.ptr(), idx_minor_upper_gpu.ptr(), idx_minor_scaling_lower_gpu.ptr(), idx_minor_scaling_upper_gpu.ptr(), \
+        kminor_start_lower_gpu.ptr(), kminor_start_upper_gpu.ptr()
+#define RRX_INTERP_ARGS \
+        flavor_gpu.ptr(), press_ref_log_gpu.ptr(), temp_ref_gpu.ptr(), press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, \
+        vmr_ref_gpu.ptr()
 
 
 // Gas optics solver longwave variant.
@@ -481,19 +436,42 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
     (void)plev;
     const int ncol = play.dim(1);
     const int nlay = play.dim(2);
-    Interp_state st;
-    compute_gas_taus(ncol, nlay, play, tlay, gas_desc, optical_props, col_dry, st);
+    const int ngas = this->gas_names.dim(1);
+    Array_gpu<Float,3> col_gas;
+    fill_col_gas(ncol, nlay, gas_desc, col_dry, col_gas);
 
-    // the one synchronous 1-element read-back of the reference (src_cuda/Gas_optics_rrtmgp.cu:1190)
-    const int sfc_lay = play({1, 1}) > play({1, nlay}) ? 1 : nlay;
-    Gas_optics_rrtmgp_kernels_cuda::compute_planck_source(
-            ncol, nlay, this->get_nband(), this->get_ngpt(), this->get_nflav(), neta, npres, ntemp, this->get_nPlanckTemp(),
-            tlay.ptr(), tlev.ptr(), tsfc.ptr(), sfc_lay,
-            st.fmajor.ptr(), st.jeta.ptr(), st.tropo.ptr(), st.jtemp.ptr(), st.jpress.ptr(),
+    // the one synchronous 1-element read-back of the reference (src_cuda/Gas_optics_rrtmgp.cu:1190), unless the caller has
+    // stated the vertical ordering (set_vertical_ordering): then the whole call is asynchronous on the current stream
+    const int sfc_lay = (vertical_ordering < 0) ? (play({1, 1}) > play({1, nlay}) ? 1 : nlay) : (vertical_ordering == 1 ? nlay : 1);
+    if (sources.planck_lite_wanted())
+    {
+        // optical depths + Planck fractions + band Planck functions in one pass; the broadband solver forms the sources
+        RRX_CALL(rrx_gas_optics_lw_fractions,
+                ncol, nlay, this->get_nband(), this->get_ngpt(), ngas, this->get_nflav(), neta, npres, ntemp, this->get_nPlanckTemp(),
+                nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o,
+                gpoint_flavor_gpu.ptr(), this->get_band_lims_gpoint_gpu().ptr(), this->get_gpoint_bands_gpu().ptr(),
+                kmajor_gpu.ptr(), kminor_lower_gpu.ptr(), kminor_upper_gpu.ptr(),
+                minor_limits_gpt_lower_gpu.ptr(), minor_limits_gpt_upper_gpu.ptr(),
+                minor_scales_with_density_lower_gpu.ptr(), minor_scales_with_density_upper_gpu.ptr(),
+                scale_by_complement_lower_gpu.ptr(), scale_by_complement_upper_gpu.ptr(),
+                idx_minor_lower_gpu.ptr(), idx_minor_upper_gpu.ptr(), idx_minor_scaling_lower_gpu.ptr(), idx_minor_scaling_upper_gpu.ptr(),
+                kminor_start_lower_gpu.ptr(), kminor_start_upper_gpu.ptr(), RRX_INTERP_ARGS,
+                play.ptr(), tlay.ptr(), tlev.ptr(), tsfc.ptr(), sfc_lay, col_gas.ptr(),
+                planck_frac_gpu.ptr(), totplnk_delta, totplnk_gpu.ptr(),
+                optical_props->get_tau().ptr(), sources.get_planck_frac().ptr(), sources.get_planck_lay().ptr(), sources.get_planck_lev().ptr(),
+                sources.get_sfc_source().ptr(), sources.get_sfc_source_jac().ptr());
+        sources.set_fractions_valid(true);
+        return;
+    }
+    RRX_CALL(rrx_gas_optics_lw_direct, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), optical_props->get_tau().ptr());
+    sources.ensure_full_arrays();
+    sources.set_fractions_valid(false);
+    RRX_CALL(rrx_planck_source_direct,
+            ncol, nlay, this->get_nband(), this->get_ngpt(), ngas, this->get_nflav(), neta, npres, ntemp, this->get_nPlanckTemp(),
+            play.ptr(), tlay.ptr(), tlev.ptr(), tsfc.ptr(), sfc_lay, col_gas.ptr(), RRX_INTERP_ARGS,
             this->get_gpoint_bands_gpu().ptr(), this->get_band_lims_gpoint_gpu().ptr(), planck_frac_gpu.ptr(),
-            temp_ref_min, totplnk_delta, totplnk_gpu.ptr(), gpoint_flavor_gpu.ptr(),
-            sources.get_sfc_source().ptr(), sources.get_lay_source().ptr(), sources.get_lev_source().ptr(),
-            sources.get_sfc_source_jac().ptr());
+            totplnk_delta, totplnk_gpu.ptr(), gpoint_flavor_gpu.ptr(),
+            sources.get_sfc_source().ptr(), sources.get_lay_source().ptr(), sources.get_lev_source().ptr(), sources.get_sfc_source_jac().ptr());
 }
 
 
@@ -510,8 +488,13 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
     (void)plev;
     const int ncol = play.dim(1);
     const int nlay = play.dim(2);
-    Interp_state st;
-    compute_gas_taus(ncol, nlay, play, tlay, gas_desc, optical_props, col_dry, st);
+    const int ngas = this->gas_names.dim(1);
+    Array_gpu<Float,3> col_gas;
+    fill_col_gas(ncol, nlay, gas_desc, col_dry, col_gas);
+    // absorption + Rayleigh + combine in one pass over the output (same arithmetic as the three reference launchers)
+    RRX_CALL(rrx_gas_optics_sw_direct, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), col_dry.ptr(), krayl_gpu.ptr(),
+            optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), static_cast<Float*>(nullptr));
+    optical_props->set_g_zero();          // g == 0: not written; materialised on the first get_g() (clouds, output)
     // External source function is constant in the column.
     RRX_CALL(rrx_spread_col, ncol, this->get_ngpt(), toa_src.ptr(), solar_source_gpu.ptr());
 }

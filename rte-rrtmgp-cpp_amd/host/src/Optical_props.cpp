@@ -88,7 +88,28 @@ void add_to(Optical_props_2str_gpu& op_inout, const Optical_props_2str_gpu& op_i
 }
 
 Source_func_lw_gpu::Source_func_lw_gpu(const int n_col, const int n_lay, const Optical_props_gpu& op) :
-    Optical_props_gpu(op),
-    sfc_source({n_col, op.get_ngpt()}), sfc_source_jac({n_col, op.get_ngpt()}),
-    lay_source({n_col, n_lay, op.get_ngpt()}), lev_source({n_col, n_lay+1, op.get_ngpt()})
+    Optical_props_gpu(op), n_col(n_col), n_lay(n_lay),
+    sfc_source({n_col, op.get_ngpt()}), sfc_source_jac({n_col, op.get_ngpt()})
 {}
+
+void Source_func_lw_gpu::ensure_full_arrays()
+{
+    if (lay_source.size() == 0) lay_source.set_dims({n_col, n_lay, get_ngpt()});
+    if (lev_source.size() == 0) lev_source.set_dims({n_col, n_lay+1, get_ngpt()});
+}
+
+Array_gpu<Float,3>& Source_func_lw_gpu::get_planck_frac() { if (pfrac.size() == 0) pfrac.set_dims({n_col, n_lay, get_ngpt()}); return pfrac; }
+Array_gpu<Float,3>& Source_func_lw_gpu::get_planck_lay()  { if (blay.size() == 0) blay.set_dims({n_col, n_lay, get_nband()}); return blay; }
+Array_gpu<Float,3>& Source_func_lw_gpu::get_planck_lev()  { if (blev.size() == 0) blev.set_dims({n_col, n_lay+1, get_nband()}); return blev; }
+
+// lay_source = pfrac*B_lay, lev_source = sqrt(pfrac*pfrac')*B_lev from the Planck-lite state (the expressions of
+// /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:260-306)
+void Source_func_lw_gpu::materialize() const
+{
+    Source_func_lw_gpu* self = const_cast<Source_func_lw_gpu*>(this);
+    self->ensure_full_arrays();
+    if (!fractions_valid) return;
+    RRX_CALL(rrx_planck_sources_from_fractions, n_col, n_lay, get_ngpt(), get_gpoint_bands_gpu().ptr(),
+             pfrac.ptr(), blay.ptr(), blev.ptr(), lay_source.ptr(), lev_source.ptr());
+    fractions_valid = false;
+}

@@ -53,6 +53,15 @@ void Rte_lw_gpu::rte_lw(
     const Bool do_jacobians = false;
     const Float* inc_flux_ptr = (inc_flux.size() == 0) ? nullptr : inc_flux.ptr();
 
+    // Planck-lite state (set by Gas_optics_rrtmgp_gpu::gas_optics): the broadband solver forms the sources itself
+    if (sources.holds_fractions() && do_broadband && n_gauss_angles == 1)
+    {
+        RRX_CALL(rrx_lw_solver_noscat_fractions, ncol, nlay, ngpt, top_at_1, secants.ptr(), gauss_wts_subset.ptr(),
+                 optical_props->get_tau().ptr(), sources.get_planck_frac().ptr(), sources.get_planck_lay().ptr(), sources.get_planck_lev().ptr(),
+                 optical_props->get_gpoint_bands_gpu().ptr(), sfc_emis_gpt.ptr(), sources.get_sfc_source().ptr(), inc_flux_ptr,
+                 gpt_flux_up.ptr(), gpt_flux_dn.ptr());
+        return;
+    }
     Rte_solver_kernels_cuda::lw_solver_noscat(
             ncol, nlay, ngpt, top_at_1, n_gauss_angles,
             secants.ptr(), gauss_wts_subset.ptr(),

@@ -150,6 +150,15 @@ namespace
 }
 
 
+void compute_heating_rate(const Array_gpu<Float,2>& flux_net, const Array_gpu<Float,2>& p_lev, Array_gpu<Float,2>& heating_rate)
+{
+    const int n_col = flux_net.dim(1), n_lev = flux_net.dim(2);
+    if (p_lev.dim(1) != n_col || p_lev.dim(2) != n_lev) throw std::runtime_error("compute_heating_rate: flux and pressure shapes differ");
+    if (heating_rate.size() == 0) heating_rate.set_dims({n_col, n_lev-1});
+    RRX_CALL(rrx_heating_rate, n_col, n_lev-1, Float(9.80665/1004.64), flux_net.ptr(), p_lev.ptr(), heating_rate.ptr());
+}
+
+
 // -------------------------------------------------------------------------------------------- longwave
 struct Radiation_solver_longwave::Workspace
 {
@@ -191,7 +200,7 @@ void Radiation_solver_longwave::solve_gpu(
     const int n_lev = p_lev.dim(2);
     const int n_gpt = this->kdist_gpu->get_ngpt();
     const int n_bnd = this->kdist_gpu->get_nband();
-    const Bool top_at_1 = p_lay({1, 1}) < p_lay({1, n_lay});
+    const Bool top_at_1 = (vertical_ordering < 0) ? Bool(p_lay({1, 1}) < p_lay({1, n_lay})) : Bool(vertical_ordering == 1);
     if (switch_cloud_optics && !cloud_optics_gpu) throw std::runtime_error("cloud optics requested but no cloud coefficients loaded");
     const bool broadband = broadband_solvers && !switch_output_bnd_fluxes;
 
@@ -203,6 +212,9 @@ void Radiation_solver_longwave::solve_gpu(
             ws->n_col = n; ws->n_lay = n_lay; ws->broadband = broadband;
             ws->optical_props = std::make_unique<Optical_props_1scl_gpu>(n, n_lay, *kdist_gpu);
             ws->sources = std::make_unique<Source_func_lw_gpu>(n, n_lay, *kdist_gpu);
+            // broadband solver: Planck fractions instead of the two source arrays (they are materialised on demand, e.g. for
+            // --output-optical)
+            ws->sources->enable_planck_lite(broadband);
             ws->gpt_flux_up.set_dims({n, n_lev, broadband ? 1 : n_gpt});
             ws->gpt_flux_dn.set_dims({n, n_lev, broadband ? 1 : n_gpt});
         }
@@ -331,7 +343,7 @@ void Radiation_solver_shortwave::solve_gpu(
     const int n_lev = p_lev.dim(2);
     const int n_gpt = this->kdist_gpu->get_ngpt();
     const int n_bnd = this->kdist_gpu->get_nband();
-    const Bool top_at_1 = p_lay({1, 1}) < p_lay({1, n_lay});
+    const Bool top_at_1 = (vertical_ordering < 0) ? Bool(p_lay({1, 1}) < p_lay({1, n_lay})) : Bool(vertical_ordering == 1);
     if (switch_cloud_optics && !cloud_optics_gpu) throw std::runtime_error("cloud optics requested but no cloud coefficients loaded");
     const bool broadband = broadband_solvers && !switch_output_bnd_fluxes;
 

@@ -93,7 +93,9 @@ void solve_radiation(int argc, char** argv)
         {"timings"          , { false, "Repeat computation 10x for run times."     }},
         {"delta-cloud"      , { true,  "delta-scaling of cloud optical properties"   }},
         {"delta-aerosol"    , { false, "delta-scaling of aerosol optical properties" }},
-        {"broadband-solvers", { true,  "Sum g-points inside the solvers (no per-g-point fluxes; off with --output-bnd-fluxes)." }}};
+        {"broadband-solvers", { true,  "Sum g-points inside the solvers (no per-g-point fluxes; off with --output-bnd-fluxes)." }},
+        {"heating-rates"    , { false, "Output layer heating rates lw_heating_rate / sw_heating_rate (K/s)." }},
+        {"async"            , { false, "Host-model mode: vertical ordering read once, solves enqueued without synchronising." }}};
 
     if (parse_command_line_options(command_line_options, argc, argv))
         return;
@@ -109,6 +111,8 @@ void solve_radiation(int argc, char** argv)
     const bool switch_delta_cloud       = command_line_options.at("delta-cloud"      ).first;
     const bool switch_delta_aerosol     = command_line_options.at("delta-aerosol"    ).first;
     const bool switch_broadband         = command_line_options.at("broadband-solvers").first;
+    const bool switch_heating_rates     = command_line_options.at("heating-rates"    ).first;
+    const bool switch_async             = command_line_options.at("async"            ).first;
 
     Status::print_message("Solver settings:");
     for (const auto& option : command_line_options)
@@ -187,6 +191,7 @@ void solve_radiation(int argc, char** argv)
         Radiation_solver_longwave rad_lw(gas_concs_gpu, "coefficients_lw.nc", switch_cloud_optics ? "cloud_coefficients_lw.nc" : "");
         rad_lw.set_column_block(col_block);
         rad_lw.set_broadband_solvers(switch_broadband);
+        if (switch_async) rad_lw.set_vertical_ordering(p_lay({1, 1}) < p_lay({1, n_lay}) ? 1 : 0);    // known on the host: no read-backs per solve
 
         const int n_bnd_lw = rad_lw.get_n_bnd_gpu();
         const int n_gpt_lw = rad_lw.get_n_gpt_gpu();
@@ -236,6 +241,12 @@ void solve_radiation(int argc, char** argv)
             output_nc.add_variable<Float>("lw_flux_up" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_up ).v(), {0, 0, 0});
             output_nc.add_variable<Float>("lw_flux_dn" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_dn ).v(), {0, 0, 0});
             output_nc.add_variable<Float>("lw_flux_net", {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_net).v(), {0, 0, 0});
+            if (switch_heating_rates)
+            {
+                Array_gpu<Float,2> hr;
+                compute_heating_rate(lw_flux_net, p_lev_gpu, hr);
+                output_nc.add_variable<Float>("lw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(hr).v(), {0, 0, 0});
+            }
             if (switch_output_bnd_fluxes)
             {
                 output_nc.add_variable<Float>("lw_bnd_flux_up" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_up ).v(), {0, 0, 0, 0});
@@ -253,6 +264,7 @@ void solve_radiation(int argc, char** argv)
                 "coefficients_sw.nc", "cloud_coefficients_sw.nc", "aerosol_optics.nc");
         rad_sw.set_column_block(col_block);
         rad_sw.set_broadband_solvers(switch_broadband);
+        if (switch_async) rad_sw.set_vertical_ordering(p_lay({1, 1}) < p_lay({1, n_lay}) ? 1 : 0);
 
         const int n_bnd_sw = rad_sw.get_n_bnd_gpu();
         const int n_gpt_sw = rad_sw.get_n_gpt_gpu();
@@ -326,6 +338,12 @@ void solve_radiation(int argc, char** argv)
             output_nc.add_variable<Float>("sw_flux_dn"    , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn    ).v(), {0, 0, 0});
             output_nc.add_variable<Float>("sw_flux_dn_dir", {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn_dir).v(), {0, 0, 0});
             output_nc.add_variable<Float>("sw_flux_net"   , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_net   ).v(), {0, 0, 0});
+            if (switch_heating_rates)
+            {
+                Array_gpu<Float,2> hr;
+                compute_heating_rate(sw_flux_net, p_lev_gpu, hr);
+                output_nc.add_variable<Float>("sw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(hr).v(), {0, 0, 0});
+            }
             if (switch_output_bnd_fluxes)
             {
                 output_nc.add_variable<Float>("sw_bnd_flux_up"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_up    ).v(), {0, 0, 0, 0});

@@ -121,3 +121,21 @@ def test_delta_scale_on_lazy_zero_g_is_the_identity():
     hand the stale g array to the kernel (C++ self-check exported by the host library)."""
     lib = ctypes.CDLL(HOSTLIB)
     assert lib.rrx_host_selftest_delta_scale_gzero() == 0
+
+
+def test_driver_heating_rates_and_async_mode(case, hip_f64):
+    """--async (vertical ordering stated once, no per-solve read-backs) gives the same fluxes; --heating-rates
+    writes -(g/cp) dF_net/dp per layer (checked against the formula on the driver's own fluxes)."""
+    assert run_driver(case["dir"], "--cloud-optics") == 0
+    _, ref = read_output(case["dir"])
+    assert run_driver(case["dir"], "--cloud-optics", "--async", "--heating-rates") == 0
+    _, out = read_output(case["dir"])
+    for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net"):
+        assert np.array_equal(out[k], ref[k]), k
+    p_lev = out["p_lev"]
+    for kind in ("lw", "sw"):
+        net = out[kind + "_flux_net"]
+        want = -(9.80665/1004.64) * (net[1:] - net[:-1]) / (p_lev[1:] - p_lev[:-1])
+        assert cases.rel_err(out[kind + "_heating_rate"], want) <= 1e-12, kind
+    # shortwave only ever heats: the net downward flux cannot grow on the way down
+    assert np.all(out["sw_heating_rate"] >= -1e-12 * np.abs(out["sw_heating_rate"]).max())
