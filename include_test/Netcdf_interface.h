@@ -4,10 +4,13 @@
  * add_variable<T>(...).insert), with the same call signatures, so load_and_init_gas_optics / solve_radiation read like
  * the reference.
  *
- * Storage backend: NetCDF-C and its headers are absent from the build image, so files are "RRXB" containers
- * (a flat, self-describing binary: named dimensions + named typed variables in C order, i.e. exactly the NetCDF data
- * model the drivers rely on). rte-rrtmgp-cpp_amd/rrxio.py reads and writes the same format. Reading real
- * rrtmgp-data NetCDF-4 files is row (f)-1 of the scope table: convert with rrxio.py where netCDF4 exists.
+ * Storage backends, chosen per file by its first bytes:
+ *  - NetCDF-4 (HDF5): the format of rrtmgp-data, aerosol_optics.nc and rte_rrtmgp_input.nc. NetCDF-C is absent from the build
+ *    image; include_test/Netcdf_hdf5.h reads and writes the NetCDF-4 on-disk conventions with the HDF5 C library
+ *    (dlopen'ed on first use). Output is NetCDF-4 when RRX_OUTPUT_FORMAT=netcdf4 (or set_output_format("netcdf4")).
+ *  - "RRXB" containers (a flat, self-describing binary: named dimensions + named typed variables in C order, i.e. exactly the
+ *    NetCDF data model the drivers rely on), which rte-rrtmgp-cpp_amd/rrxio.py reads and writes without any library: the
+ *    format of the synthetic test inputs and the default output format.
  *
  * File layout (little endian):  "RRXB1\0\0\0" | u32 ndim | ndim x {u32 len, name, i64 size}
  *                               | u32 nvar | nvar x {u32 len, name, u8 dtype, u32 rank, rank x {u32 len, dimname}, i64 nbytes, data}
@@ -16,6 +19,7 @@
 #ifndef NETCDF_INTERFACE_H
 #define NETCDF_INTERFACE_H
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -24,12 +28,12 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include "Netcdf_hdf5.h"
 
 enum class Netcdf_mode { Create, Read, Write };
 
 namespace rrxb
 {
-    struct Var { uint8_t dtype; std::vector<std::string> dims; std::vector<char> bytes; };
     template<typename T> struct Dtype;
     template<> struct Dtype<double>      { static constexpr uint8_t id = 0; };
     template<> struct Dtype<float>       { static constexpr uint8_t id = 1; };
@@ -136,16 +140,37 @@ class Netcdf_handle
             dirty = true;
         }
 
+        // every dimension and variable of another file (any backend), e.g. to convert NetCDF-4 <-> RRXB
+        void copy_contents_of(const Netcdf_handle& o)
+        {
+            for (const auto& d : o.dim_order) if (!dims.count(d)) { dims[d] = o.dims.at(d); dim_order.push_back(d); }
+            for (const auto& n : o.var_order)
+            {
+                const rrxb::Var& v = o.var(n);
+                rrxb::Var c; c.dtype = v.dtype; c.dims = v.dims; c.bytes = v.bytes;
+                if (!vars.count(n)) var_order.push_back(n);
+                vars[n] = std::move(c);
+            }
+            dirty = true;
+        }
+        const std::vector<std::string>& variable_names() const { return var_order; }
+
     protected:
         const rrxb::Var& var(const std::string& name) const
         {
             auto it = vars.find(name);
             if (it == vars.end()) throw std::runtime_error("variable " + name + " not found");
+            if (it->second.loader)                 // lazy backend (NetCDF-4): the data is read on first access
+            {
+                auto loader = std::move(it->second.loader);
+                it->second.loader = nullptr;
+                loader(it->second);
+            }
             return it->second;
         }
         std::map<std::string, int64_t> dims;
         std::vector<std::string> dim_order;
-        std::map<std::string, rrxb::Var> vars;
+        mutable std::map<std::string, rrxb::Var> vars;
         std::vector<std::string> var_order;
         bool dirty = false;
 };
@@ -171,9 +196,23 @@ class Netcdf_file : public Netcdf_handle
         }
         ~Netcdf_file() { try { sync(); } catch (...) {} }
 
+        // "rrxb" (default) or "netcdf4"; the environment variable RRX_OUTPUT_FORMAT sets the default of the process
+        void set_output_format(const std::string& fmt) { netcdf4_out = (fmt == "netcdf4"); }
+
         void sync()
         {
             if (mode == Netcdf_mode::Read || !dirty) return;
+            if (netcdf4_out)
+            {
+#ifdef RRX_HAVE_HDF5_HEADERS
+                for (auto& kv : vars) (void)var(kv.first);          // anything still lazy is loaded before the file is replaced
+                rrx_h5::write_file(file_name, dims, dim_order, vars, var_order);
+                dirty = false;
+                return;
+#else
+                throw std::runtime_error("NetCDF-4 output needs the HDF5 headers at build time");
+#endif
+            }
             std::ofstream f(file_name, std::ios::binary | std::ios::trunc);
             if (!f) throw std::runtime_error("cannot write " + file_name);
             auto put_u32 = [&](uint32_t v) { f.write(reinterpret_cast<char*>(&v), 4); };
@@ -185,7 +224,7 @@ class Netcdf_file : public Netcdf_handle
             put_u32(uint32_t(var_order.size()));
             for (const auto& n : var_order)
             {
-                const rrxb::Var& v = vars[n];
+                const rrxb::Var& v = var(n);
                 put_str(n); f.write(reinterpret_cast<const char*>(&v.dtype), 1);
                 put_u32(uint32_t(v.dims.size()));
                 for (const auto& d : v.dims) put_str(d);
@@ -198,6 +237,16 @@ class Netcdf_file : public Netcdf_handle
     private:
         void read()
         {
+            if (rrx_h5::is_hdf5(file_name))
+            {
+#ifdef RRX_HAVE_HDF5_HEADERS
+                rrx_h5::read_file(file_name, dims, dim_order, vars, var_order);
+                netcdf4_out = true;                                  // a file opened for writing keeps its format
+                return;
+#else
+                throw std::runtime_error(file_name + " is a NetCDF-4 file: this build has no HDF5 support");
+#endif
+            }
             std::ifstream f(file_name, std::ios::binary);
             if (!f) throw std::runtime_error("cannot open " + file_name);
             char magic[8]; f.read(magic, 8);
@@ -222,5 +271,6 @@ class Netcdf_file : public Netcdf_handle
         }
         std::string file_name;
         Netcdf_mode mode;
+        bool netcdf4_out = []{ const char* e = std::getenv("RRX_OUTPUT_FORMAT"); return e != nullptr && std::string(e) == "netcdf4"; }();
 };
 #endif

@@ -2,8 +2,11 @@
 // tests (tests/test_gpu_host_classes.py). Each returns 0 on success and a non-zero code naming the failed check.
 #include <cmath>
 #include <vector>
+#include <cstdio>
+#include <string>
 #include "Array.h"
 #include "Optical_props.h"
+#include "Netcdf_interface.h"
 
 namespace
 {
@@ -55,5 +58,90 @@ int rrx_host_selftest_delta_scale_gzero(void)
         return 0;
     }
     catch (const std::exception&) { return 100; }
+}
+
+// Any supported file (NetCDF-4 or RRXB, recognised by its first bytes) rewritten in the other format: "rrxb" or "netcdf4".
+int rrx_host_netcdf_convert(const char* in_path, const char* out_path, const char* format)
+{
+    try
+    {
+        Netcdf_file in(in_path, Netcdf_mode::Read);
+        Netcdf_file out(out_path, Netcdf_mode::Create);
+        out.set_output_format(format);
+        out.copy_contents_of(in);
+        out.sync();
+        return 0;
+    }
+    catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_convert: %s\n", e.what()); return 1; }
+}
+
+// NetCDF-4 round trip through the HDF5 backend: dimensions, dimension order of each variable, f64 / f32 / i32 / char data,
+// a scalar, a coordinate variable; no device involved.
+int rrx_host_selftest_netcdf4(const char* dir)
+{
+    try
+    {
+        const std::string path = std::string(dir) + "/roundtrip.nc";
+        std::vector<double> a(2*3*4); for (size_t i=0; i<a.size(); ++i) a[i] = 0.5*double(i) - 3.25;
+        std::vector<float> b(4); for (size_t i=0; i<b.size(); ++i) b[i] = 1.5f*float(i);
+        std::vector<int> c(3*2); for (size_t i=0; i<c.size(); ++i) c[i] = int(i)*7 - 5;
+        const std::string names = "h2o     co2     o3      ";
+        {
+            Netcdf_file f(path, Netcdf_mode::Create);
+            f.set_output_format("netcdf4");
+            f.add_dimension("lay", 2); f.add_dimension("y", 3); f.add_dimension("x", 4); f.add_dimension("pair", 2);
+            f.add_dimension("absorber", 3); f.add_dimension("string_len", 8);
+            f.add_variable<double>("p_lay", {"lay", "y", "x"}).insert(a, {0, 0, 0});
+            f.add_variable<float>("x", {"x"}).insert(b, {0});                                   // coordinate variable
+            f.add_variable<int>("limits", {"y", "pair"}).insert(c, {0, 0});
+            f.add_variable<char>("gas_names", {"absorber", "string_len"}).insert(std::vector<char>(names.begin(), names.end()), {0, 0});
+            f.add_variable<double>("tsi_default").insert(1360.85, {});
+        }
+        FILE* fp = std::fopen(path.c_str(), "rb");
+        unsigned char magic[4] = {0};
+        if (!fp || std::fread(magic, 1, 4, fp) != 4 || magic[1] != 'H' || magic[2] != 'D' || magic[3] != 'F') return 1;
+        std::fclose(fp);
+        Netcdf_file r(path, Netcdf_mode::Read);
+        if (r.get_dimension_size("lay") != 2 || r.get_dimension_size("y") != 3 || r.get_dimension_size("x") != 4 || r.get_dimension_size("string_len") != 8) return 2;
+        const auto d = r.get_variable_dimensions("p_lay");
+        if (d.size() != 3 || d.at("lay") != 2 || d.at("y") != 3 || d.at("x") != 4) return 3;
+        if (r.get_variable<double>("p_lay", {2, 3, 4}) != a) return 4;
+        if (r.get_variable<float>("x", {4}) != b) return 5;
+        if (r.get_variable<int>("limits", {3, 2}) != c) return 6;
+        const std::vector<char> g = r.get_variable<char>("gas_names", {3, 8});
+        if (std::string(g.begin(), g.end()) != names) return 7;
+        if (r.get_variable<double>("tsi_default") != 1360.85) return 8;
+        if (!r.variable_exists("limits") || r.variable_exists("nope")) return 9;
+        if (r.get_variable<float>("p_lay", {2, 3, 4})[5] != float(a[5])) return 10;              // type conversion on read
+        return 0;
+    }
+    catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_selftest_netcdf4: %s\n", e.what()); return 100; }
+}
+
+// The one real NetCDF-4 file of the reference tree (data/aerosol_optics.nc, written by netCDF4-python): dimensions and a few
+// values, against numbers obtained independently with h5dump. Returns 0, or the index of the first check that failed.
+int rrx_host_selftest_read_aerosol_file(const char* path)
+{
+    try
+    {
+        Netcdf_file f(path, Netcdf_mode::Read);
+        if (f.get_dimension_size("band_sw") != 14 || f.get_dimension_size("relative_humidity") != 12 ||
+            f.get_dimension_size("hydrophilic") != 7 || f.get_dimension_size("hydrophobic") != 14) return 1;
+        const auto d = f.get_variable_dimensions("mass_ext_sw_hydrophilic");
+        if (d.size() != 3 || d.at("hydrophilic") != 7 || d.at("relative_humidity") != 12 || d.at("band_sw") != 14) return 2;
+        const std::vector<double> m = f.get_variable<double>("mass_ext_sw_hydrophilic", {7, 12, 14});
+        const double want_m[14] = {123.197, 166.189, 433.198, 245.302, 317.993, 488.143, 809.627, 1028.66, 1760, 3071.97, 4759.77, 6852.52, 8921.85, 10958.8};
+        for (int i=0; i<14; ++i) if (std::abs(m[(3*12 + 5)*14 + i] - want_m[i]) > 6e-6*want_m[i]) return 3;
+        const std::vector<double> s = f.get_variable<double>("ssa_sw_hydrophobic", {14, 14});
+        const double want_s[6] = {0.152659, 0.11512, 0.719504, 0.963146, 0.96859, 0.998038};
+        for (int i=0; i<6; ++i) if (std::abs(s[13*14 + i] - want_s[i]) > 6e-6) return 4;
+        const std::vector<double> rh = f.get_variable<double>("relative_humidity1", {12});
+        const double want_rh[12] = {0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.85, 0.9, 0.95};
+        for (int i=0; i<12; ++i) if (std::abs(rh[i] - want_rh[i]) > 1e-6) return 5;
+        const std::vector<double> wn = f.get_variable<double>("wavenumber1_sw", {14});
+        if (wn[0] != 820. || wn[1] != 2600. || wn[13] != 38000.) return 6;
+        return 0;
+    }
+    catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_selftest_read_aerosol_file: %s\n", e.what()); return 100; }
 }
 }
