@@ -272,6 +272,14 @@ int rrx_expand_and_transpose##SFX(int ncol, int nbnd, const int* band_lims_gpt, 
 int rrx_spread_col##SFX(int ncol, int ngpt, F* toa_src, const F* solar_source, void* stream); \
 /* src_test/Radiation_solver.cu scaling_to_subset: toa_src(icol,igpt) *= tsi_scaling(icol) */ \
 int rrx_scaling_to_subset##SFX(int ncol, int ngpt, F* toa_src, const F* tsi_scaling, void* stream); \
+/* src_cuda/Aerosol_optics.cu:36-263 + Aerosol_optics_gpu::aerosol_optics (:305-345): CAMS aerosol optics per band in one kernel. \
+   aermr: HOST array of 11 device pointers (aermr01..aermr11), each (ncol,nlay) or, where aermr_per_column[a] == 0, one (nlay) \
+   profile shared by all columns (the reference materialises the broadcast, fill_aerosols_3d); aermr_per_column may be NULL \
+   (all per column). rh, tau, ssa, g: (ncol,nlay[,nbnd]); plev (ncol,nlay+1); rh_upper (nhum); hydrophobic tables \
+   (nbnd,nphobic), hydrophilic tables (nbnd,nhum,nphilic), band index fastest (Radiation_solver.cu:366-401) */ \
+int rrx_aerosol_optics##SFX(int ncol, int nlay, int nbnd, int nhum, int nphobic, int nphilic, const F* const* aermr, const int* aermr_per_column, \
+        const F* rh, const F* plev, const F* rh_upper, const F* mext_phobic, const F* ssa_phobic, const F* g_phobic, \
+        const F* mext_philic, const F* ssa_philic, const F* g_philic, F* tau, F* ssa, F* g, void* stream); \
 /* src_cuda/Cloud_optics.cu:31-127,181-329: LUT cloud optics per band; luts are (nsize,nbnd) */ \
 int rrx_cloud_optics_2str##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
         F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \

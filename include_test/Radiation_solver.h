@@ -128,6 +128,7 @@ class Radiation_solver_shortwave
     private:
         std::unique_ptr<Gas_optics_rrtmgp_gpu> kdist_gpu;
         std::unique_ptr<Cloud_optics_gpu> cloud_optics_gpu;
+        std::unique_ptr<Aerosol_optics_gpu> aerosol_optics_gpu;
         Rte_sw_gpu rte_sw;
         int vertical_ordering = -1;
         int n_col_block = 16384;

@@ -326,6 +326,20 @@ class CpuKernels:
         self.lib.call("oracle_cloud_optics_2str", *args, tau, ssa, g)
         return tau, ssa, g
 
+    def aerosol_optics(self, lut, aermr, rh, plev):
+        """aermr: the 11 mixing ratios aermr01..11, each (nlay, ncol) or an (nlay,) profile; lut: rh_upper (nhum,), hydrophobic
+        tables (nphobic, nbnd), hydrophilic tables (nphilic, nhum, nbnd)."""
+        assert self.is_oracle
+        nlay, ncol = rh.shape
+        nbnd = lut["mext_phobic"].shape[-1]
+        nhum = lut["rh_upper"].shape[0]
+        full = [np.ascontiguousarray(np.broadcast_to(m if m.ndim == 2 else m[:, None], (nlay, ncol))) for m in aermr]
+        tau = self.empty((nbnd, nlay, ncol)); ssa = self.empty((nbnd, nlay, ncol)); g = self.empty((nbnd, nlay, ncol))
+        self.lib.call("oracle_aerosol_optics_2str", ncol, nlay, nbnd, nhum, *full, rh, plev, lut["rh_upper"],
+                      lut["mext_phobic"], lut["ssa_phobic"], lut["g_phobic"], lut["mext_philic"], lut["ssa_philic"], lut["g_philic"],
+                      tau, ssa, g)
+        return tau, ssa, g
+
     def cloud_optics_1scl(self, lut, clwp, ciwp, reliq, deice):
         assert self.is_oracle
         args, shp = self._cloud_args(lut, clwp, ciwp, reliq, deice)

@@ -841,4 +841,54 @@ void oracle_cloud_optics_1scl(
             tau[i + ibnd*ncl] = (lt - lts) + (it - its);
         }
 }
+
+// src/Aerosol_optics.cpp:24-36 (rh_class), :38-157 (compute_all_from_table), :176-224 (finalisation). Species in the order of
+// :56 (SS1 SS2 SS3 DU1 DU2 DU3 OM1 OM2 BC1 BC2 SU); tables: hydrophobic (nbnd, nphobic), hydrophilic (nbnd, nhum, nphilic),
+// band fastest. Two deliberate differences from that text, both shared with the GPU text (src_cuda/Aerosol_optics.cu:65):
+// dp is taken as |dp| (the CPU text gives negative optical depths for a top-first ordering), and a humidity above the last
+// class bound uses the last class (the reference reads past the table).
+void oracle_aerosol_optics_2str(
+        int* ncol_, int* nlay_, int* nbnd_, int* nhum_,
+        Float* aermr01, Float* aermr02, Float* aermr03, Float* aermr04, Float* aermr05, Float* aermr06,
+        Float* aermr07, Float* aermr08, Float* aermr09, Float* aermr10, Float* aermr11,
+        Float* rh, Float* plev, Float* rh_classes,
+        Float* mext_phobic, Float* ssa_phobic, Float* g_phobic,
+        Float* mext_philic, Float* ssa_philic, Float* g_philic,
+        Float* tau, Float* ssa, Float* g)
+{
+    const int ncol=*ncol_, nlay=*nlay_, nbnd=*nbnd_, nhum=*nhum_;
+    const Float eps = std::numeric_limits<Float>::epsilon();
+    const size_t ncl = size_t(ncol)*nlay;
+    // {mixing ratio, hydrophilic?, 1-based table column} per species, in accumulation order
+    struct Species { const Float* mmr; bool philic; int col; };
+    const Species list[11] = {
+        {aermr01, true, 1}, {aermr02, true, 2}, {aermr03, true, 3},
+        {aermr04, false, 1}, {aermr05, false, 8}, {aermr06, false, 6},
+        {aermr08, false, 10}, {aermr07, true, 4},
+        {aermr09, false, 11}, {aermr10, false, 11},
+        {aermr11, true, 5}};
+    for (int ibnd=0; ibnd<nbnd; ++ibnd)
+        for (size_t i=0; i<ncl; ++i)
+        {
+            const Float dpg = std::abs(plev[i] - plev[i + ncol]) / Float(9.81);
+            int ihum = 1;
+            while (ihum < nhum && rh_classes[ihum-1] < rh[i]) ++ihum;
+            Float tau_local = 0, taussa_local = 0, taussag_local = 0;
+            for (const Species& sp : list)
+            {
+                const size_t k = sp.philic ? size_t(ibnd) + size_t(ihum-1)*nbnd + size_t(sp.col-1)*nbnd*nhum
+                                           : size_t(ibnd) + size_t(sp.col-1)*nbnd;
+                const Float mext = sp.philic ? mext_philic[k] : mext_phobic[k];
+                const Float w    = sp.philic ? ssa_philic[k]  : ssa_phobic[k];
+                const Float asy  = sp.philic ? g_philic[k]    : g_phobic[k];
+                const Float local_od = sp.mmr[i] * dpg * mext;
+                tau_local += local_od;
+                taussa_local += local_od * w;
+                taussag_local += local_od * w * asy;
+            }
+            tau[i + ibnd*ncl] = tau_local;
+            ssa[i + ibnd*ncl] = taussa_local / std::max(tau_local, eps);
+            g  [i + ibnd*ncl] = taussag_local / std::max(taussa_local, eps);
+        }
+}
 }

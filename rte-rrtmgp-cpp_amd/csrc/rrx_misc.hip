@@ -292,6 +292,74 @@ __global__ void cloud_optics_kernel(const size_t ncl, const int nsize_liq, const
     }
 }
 
+// ---- aerosol optics: /root/reference/src/Aerosol_optics.cpp:24-224, src_cuda/Aerosol_optics.cu:9-263 ----
+// 11 CAMS species, each a (mixing ratio, table column) pair; hydrophilic species are looked up in the humidity class of the cell.
+// One thread per (column, layer): humidity class, dp/g and the 11 mixing ratios are read once and reused for every band
+// (the reference launches a thread per (column, layer, band) and re-reads them nbnd times; its three temporaries
+// tau / tau*ssa / tau*ssa*g and the second, finalising kernel are folded into this one). Species are accumulated in the
+// order of the CPU text (SS1 SS2 SS3 DU1 DU2 DU3 OM1 OM2 BC1 BC2 SU), which the oracle restates.
+template<typename F> struct AerosolSpecies { const F* mmr[11]; int per_column[11]; };
+
+// {index into aermr01..11, hydrophilic?, 0-based table column}: Aerosol_optics.cpp:58-157
+__constant__ const signed char aerosol_species_table[11][3] = {
+    {0, 1, 0}, {1, 1, 1}, {2, 1, 2},          // SS1 SS2 SS3 : aermr01..03, hydrophilic 1..3
+    {3, 0, 0}, {4, 0, 7}, {5, 0, 5},          // DU1 DU2 DU3 : aermr04..06, hydrophobic 1, 8, 6
+    {7, 0, 9}, {6, 1, 3},                     // OM1 (aermr08, hydrophobic 10), OM2 (aermr07, hydrophilic 4)
+    {8, 0, 10}, {9, 0, 10},                   // BC1 BC2 : aermr09, aermr10, hydrophobic 11
+    {10, 1, 4}};                              // SU : aermr11, hydrophilic 5
+
+template<typename F>
+__global__ void aerosol_optics_kernel(const int ncol, const int nlay, const int nbnd, const int nhum,
+        const AerosolSpecies<F> sp, const F* __restrict__ rh, const F* __restrict__ plev, const F* __restrict__ rh_upper,
+        const F* __restrict__ mext_phobic, const F* __restrict__ ssa_phobic, const F* __restrict__ g_phobic,
+        const F* __restrict__ mext_philic, const F* __restrict__ ssa_philic, const F* __restrict__ g_philic,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
+{
+    const size_t ncl = size_t(ncol)*nlay;
+    const F eps = Lim<F>::eps();
+    RRX_GRID_STRIDE(i, ncl)
+    {
+        const int ilay = int(i / ncol), icol = int(i - size_t(ilay)*ncol);
+        // first class whose upper bound reaches the cell's humidity (Aerosol_optics.cpp:24-36); the reference reads past the
+        // table for rh above the last bound, here the last class is used
+        const F rh_c = rh[i];
+        int ihum = 0;
+        while (ihum < nhum-1 && rh_upper[ihum] < rh_c) ++ihum;
+        const F dpg = abs(plev[i] - plev[i + ncol]) / F(9.81);
+        F od[11];
+        int lut[11];
+        #pragma unroll
+        for (int s=0; s<11; ++s)
+        {
+            const int im = aerosol_species_table[s][0];
+            const bool philic = aerosol_species_table[s][1];
+            od[s] = sp.mmr[im][sp.per_column[im] ? i : size_t(ilay)] * dpg;
+            lut[s] = philic ? (ihum + aerosol_species_table[s][2]*nhum)*nbnd : aerosol_species_table[s][2]*nbnd;
+        }
+        (void)icol;
+        for (int ibnd=0; ibnd<nbnd; ++ibnd)
+        {
+            F t = F(0.), ts = F(0.), tsg = F(0.);
+            #pragma unroll
+            for (int s=0; s<11; ++s)
+            {
+                const bool philic = aerosol_species_table[s][1];
+                const int k = lut[s] + ibnd;
+                const F local_od = od[s] * (philic ? mext_philic[k] : mext_phobic[k]);
+                const F w = philic ? ssa_philic[k] : ssa_phobic[k];
+                const F a = philic ? g_philic[k] : g_phobic[k];
+                t += local_od;
+                ts += local_od * w;
+                tsg += local_od * w * a;
+            }
+            const size_t o = i + size_t(ibnd)*ncl;
+            tau[o] = t;
+            ssa[o] = ts / max(t, eps);
+            g[o] = tsg / max(ts, eps);
+        }
+    }
+}
+
 template<typename F>
 __global__ void subset_cols_kernel(const int ncol_full, const size_t nrest, const int col_s, const int ncol_sub, const F* __restrict__ in, F* __restrict__ out)
 {
@@ -413,6 +481,14 @@ int rrx_spread_col##SFX(int ncol, int ngpt, F* toa_src, const F* solar_source, v
 { RRX_TRY spread_col_kernel<F><<<grid1d(size_t(ncol)*ngpt), 256, 0, ST>>>(ncol, ngpt, toa_src, solar_source); RRX_CATCH("rrx_spread_col") } \
 int rrx_scaling_to_subset##SFX(int ncol, int ngpt, F* toa_src, const F* tsi_scaling, void* stream) \
 { RRX_TRY scale_cols_kernel<F><<<grid1d(size_t(ncol)*ngpt), 256, 0, ST>>>(ncol, ngpt, toa_src, tsi_scaling); RRX_CATCH("rrx_scaling_to_subset") } \
+int rrx_aerosol_optics##SFX(int ncol, int nlay, int nbnd, int nhum, int nphobic, int nphilic, const F* const* aermr, const int* aermr_per_column, \
+        const F* rh, const F* plev, const F* rh_upper, const F* mext_phobic, const F* ssa_phobic, const F* g_phobic, \
+        const F* mext_philic, const F* ssa_philic, const F* g_philic, F* tau, F* ssa, F* g, void* stream) \
+{ RRX_TRY if (nphobic < 11 || nphilic < 5) throw std::runtime_error("aerosol tables need >= 11 hydrophobic and >= 5 hydrophilic species"); \
+  if (nhum < 1) throw std::runtime_error("no humidity classes"); \
+  AerosolSpecies<F> sp; for (int a=0; a<11; ++a) { if (!aermr[a]) throw std::runtime_error("missing aerosol mixing ratio"); sp.mmr[a] = aermr[a]; sp.per_column[a] = aermr_per_column ? aermr_per_column[a] : 1; } \
+  aerosol_optics_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, nbnd, nhum, sp, rh, plev, rh_upper, \
+      mext_phobic, ssa_phobic, g_phobic, mext_philic, ssa_philic, g_philic, tau, ssa, g); RRX_CATCH("rrx_aerosol_optics") } \
 int rrx_cloud_optics_2str##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
         F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
         const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \

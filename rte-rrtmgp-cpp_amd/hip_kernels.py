@@ -409,6 +409,25 @@ class HipKernels:
                 clwp, ciwp, reliq, deice, tau, ssa, g)
         return tau, ssa, g
 
+    def aerosol_optics(self, lut, aermr, rh, plev):
+        """CAMS aerosol optics per band (src_cuda/Aerosol_optics.cu). aermr: aermr01..11, each (nlay, ncol) or an (nlay,)
+        profile shared by all columns (read in place, not broadcast)."""
+        nlay, ncol = rh.shape
+        nphobic, nbnd = lut["mext_phobic"].shape
+        nphilic, nhum = lut["mext_philic"].shape[:2]
+        if len(aermr) != 11:
+            raise ValueError("aerosol optics needs the 11 mixing ratios aermr01..aermr11")
+        for m in aermr:
+            if tuple(m.shape) not in ((nlay, ncol), (nlay,)):
+                raise ValueError("aerosol mixing ratio must be (nlay, ncol) or (nlay,)")
+        ptrs = (ctypes.c_void_p * 11)(*[m.data_ptr() for m in aermr])
+        per_col = (ctypes.c_int * 11)(*[1 if m.dim() == 2 else 0 for m in aermr])
+        tau = self.empty((nbnd, nlay, ncol)); ssa = self.empty((nbnd, nlay, ncol)); g = self.empty((nbnd, nlay, ncol))
+        self._c("aerosol_optics", ncol, nlay, nbnd, nhum, nphobic, nphilic, ptrs, per_col, rh, plev, lut["rh_upper"],
+                lut["mext_phobic"], lut["ssa_phobic"], lut["g_phobic"], lut["mext_philic"], lut["ssa_philic"], lut["g_philic"],
+                tau, ssa, g)
+        return tau, ssa, g
+
     def cloud_optics_1scl(self, lut, clwp, ciwp, reliq, deice):
         nlay, ncol = clwp.shape
         nbnd = lut["lut_extliq"].shape[0]

@@ -140,6 +140,26 @@ namespace
                                 lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice);
     }
 
+    // /root/reference/src_test/Radiation_solver.cu:366-401. The file holds no band limits for these tables: the reference hands
+    // over an all-zero (2, n_band) array, and so does this loader (only the band COUNT is used, by add_to).
+    Aerosol_optics_gpu load_and_init_aerosol_optics(const std::string& coef_file)
+    {
+        Netcdf_file coef_nc(coef_file, Netcdf_mode::Read);
+        const int n_band = coef_nc.get_dimension_size("band_sw");
+        const int n_hum = coef_nc.get_dimension_size("relative_humidity");
+        const int n_philic = coef_nc.get_dimension_size("hydrophilic");
+        const int n_phobic = coef_nc.get_dimension_size("hydrophobic");
+        Array<Float,2> band_lims_wvn({2, n_band});
+        Array<Float,2> mext_phobic(coef_nc.get_variable<Float>("mass_ext_sw_hydrophobic", {n_phobic, n_band}), {n_band, n_phobic});
+        Array<Float,2> ssa_phobic(coef_nc.get_variable<Float>("ssa_sw_hydrophobic", {n_phobic, n_band}), {n_band, n_phobic});
+        Array<Float,2> g_phobic(coef_nc.get_variable<Float>("asymmetry_sw_hydrophobic", {n_phobic, n_band}), {n_band, n_phobic});
+        Array<Float,3> mext_philic(coef_nc.get_variable<Float>("mass_ext_sw_hydrophilic", {n_philic, n_hum, n_band}), {n_band, n_hum, n_philic});
+        Array<Float,3> ssa_philic(coef_nc.get_variable<Float>("ssa_sw_hydrophilic", {n_philic, n_hum, n_band}), {n_band, n_hum, n_philic});
+        Array<Float,3> g_philic(coef_nc.get_variable<Float>("asymmetry_sw_hydrophilic", {n_philic, n_hum, n_band}), {n_band, n_hum, n_philic});
+        Array<Float,1> rh_upper(coef_nc.get_variable<Float>("relative_humidity2", {n_hum}), {n_hum});
+        return Aerosol_optics_gpu(band_lims_wvn, rh_upper, mext_phobic, ssa_phobic, g_phobic, mext_philic, ssa_philic, g_philic);
+    }
+
     // contiguous column blocks {1-based start, size}
     std::vector<std::pair<int,int>> column_blocks(const int n_col, const int n_col_block)
     {
@@ -292,7 +312,7 @@ struct Radiation_solver_shortwave::Workspace
     int n_col = 0, n_lay = 0;
     bool broadband = false;
     std::unique_ptr<Optical_props_arry_gpu> optical_props;
-    std::unique_ptr<Optical_props_2str_gpu> cloud_optical_props;
+    std::unique_ptr<Optical_props_2str_gpu> cloud_optical_props, aerosol_optical_props;
     Array_gpu<Float,3> gpt_flux_up, gpt_flux_dn, gpt_flux_dn_dir;
 };
 
@@ -304,11 +324,15 @@ Radiation_solver_shortwave::Radiation_solver_shortwave(
         const std::string& file_name_cloud,
         const std::string& file_name_aerosol)
 {
-    (void)file_name_aerosol;
-    if (switch_aerosol_optics) throw std::runtime_error("aerosol optics is outside the scope of this build (DESIGN.md section 9)");
     this->kdist_gpu = std::make_unique<Gas_optics_rrtmgp_gpu>(load_and_init_gas_optics(gas_concs, file_name_gas));
     if (switch_cloud_optics)
         this->cloud_optics_gpu = std::make_unique<Cloud_optics_gpu>(load_and_init_cloud_optics(file_name_cloud));
+    if (switch_aerosol_optics)
+    {
+        this->aerosol_optics_gpu = std::make_unique<Aerosol_optics_gpu>(load_and_init_aerosol_optics(file_name_aerosol));
+        if (this->aerosol_optics_gpu->get_nband() != this->kdist_gpu->get_nband())
+            throw std::runtime_error("aerosol optics tables and the shortwave k-distribution disagree in the number of bands");
+    }
 }
 
 void Radiation_solver_shortwave::solve_gpu(
@@ -336,8 +360,7 @@ void Radiation_solver_shortwave::solve_gpu(
         Array_gpu<Float,3>& sw_bnd_flux_up, Array_gpu<Float,3>& sw_bnd_flux_dn,
         Array_gpu<Float,3>& sw_bnd_flux_dn_dir, Array_gpu<Float,3>& sw_bnd_flux_net)
 {
-    (void)t_lev; (void)rh; (void)aerosol_concs; (void)switch_delta_aerosol;
-    if (switch_aerosol_optics) throw std::runtime_error("aerosol optics is outside the scope of this build (DESIGN.md section 9)");
+    (void)t_lev;
     const int n_col = p_lay.dim(1);
     const int n_lay = p_lay.dim(2);
     const int n_lev = p_lev.dim(2);
@@ -345,6 +368,7 @@ void Radiation_solver_shortwave::solve_gpu(
     const int n_bnd = this->kdist_gpu->get_nband();
     const Bool top_at_1 = (vertical_ordering < 0) ? Bool(p_lay({1, 1}) < p_lay({1, n_lay})) : Bool(vertical_ordering == 1);
     if (switch_cloud_optics && !cloud_optics_gpu) throw std::runtime_error("cloud optics requested but no cloud coefficients loaded");
+    if (switch_aerosol_optics && !aerosol_optics_gpu) throw std::runtime_error("aerosol optics requested but no aerosol coefficients loaded");
     const bool broadband = broadband_solvers && !switch_output_bnd_fluxes;
 
     auto prepare = [&](std::shared_ptr<Workspace>& ws, const int n)
@@ -359,6 +383,8 @@ void Radiation_solver_shortwave::solve_gpu(
         }
         if (switch_cloud_optics && !ws->cloud_optical_props)
             ws->cloud_optical_props = std::make_unique<Optical_props_2str_gpu>(n, n_lay, *cloud_optics_gpu);
+        if (switch_aerosol_optics && !ws->aerosol_optical_props)
+            ws->aerosol_optical_props = std::make_unique<Optical_props_2str_gpu>(n, n_lay, *aerosol_optics_gpu);
     };
 
     for (const auto& blk : column_blocks(n_col, std::max(1, n_col_block)))
@@ -392,6 +418,17 @@ void Radiation_solver_shortwave::solve_gpu(
             if (switch_delta_cloud)
                 ws.cloud_optical_props->delta_scale();
             add_to(dynamic_cast<Optical_props_2str_gpu&>(*ws.optical_props), *ws.cloud_optical_props);
+        }
+
+        if (switch_aerosol_optics)
+        {
+            // the block's own columns (the reference subsets (1, n_col) here, Radiation_solver.cu:796, which is only right for
+            // a single block)
+            Aerosol_concs_gpu aerosol_concs_subset(aerosol_concs, col_s, n_in);
+            aerosol_optics_gpu->aerosol_optics(aerosol_concs_subset, sub2(rh, n_lay), p_lev_s, *ws.aerosol_optical_props);
+            if (switch_delta_aerosol)
+                ws.aerosol_optical_props->delta_scale();
+            add_to(dynamic_cast<Optical_props_2str_gpu&>(*ws.optical_props), *ws.aerosol_optical_props);
         }
 
         if (switch_output_optical)

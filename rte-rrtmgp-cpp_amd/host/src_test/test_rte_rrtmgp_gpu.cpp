@@ -87,7 +87,7 @@ void solve_radiation(int argc, char** argv)
         {"longwave"         , { true,  "Enable computation of longwave radiation." }},
         {"fluxes"           , { true,  "Enable computation of fluxes."             }},
         {"cloud-optics"     , { false, "Enable cloud optics."                      }},
-        {"aerosol-optics"   , { false, "Enable aerosol optics (not available in this build)." }},
+        {"aerosol-optics"   , { false, "Enable aerosol optics."                       }},
         {"output-optical"   , { false, "Enable output of optical properties."      }},
         {"output-bnd-fluxes", { false, "Enable output of band fluxes."             }},
         {"timings"          , { false, "Repeat computation 10x for run times."     }},
@@ -289,7 +289,27 @@ void solve_radiation(int argc, char** argv)
 
         Array_gpu<Float,1> mu0_gpu(mu0), tsi_scaling_gpu(tsi_scaling);
         Array_gpu<Float,2> sfc_alb_dir_gpu(sfc_alb_dir), sfc_alb_dif_gpu(sfc_alb_dif), rh_gpu;
-        Aerosol_concs_gpu aerosol_concs_gpu;
+        // /root/reference/src_test/test_rte_rrtmgp.cu:72-103,303-320: relative humidity and the 11 CAMS mixing ratios, each
+        // either an (n_lay) profile or an (n_lay, y, x) field
+        Aerosol_concs aerosol_concs;
+        if (switch_aerosol_optics)
+        {
+            rh_gpu = Array<Float,2>(input_nc.get_variable<Float>("rh", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+            for (int i=1; i<=11; ++i)
+            {
+                const std::string name = std::string(i < 10 ? "aermr0" : "aermr") + std::to_string(i);
+                if (!input_nc.variable_exists(name))
+                    throw std::runtime_error("Aerosol type \"" + name + "\" not available in input file.");
+                const std::map<std::string, int> dims = input_nc.get_variable_dimensions(name);
+                if (dims.size() == 1 && dims.count("lay"))
+                    aerosol_concs.set_vmr(name, Array<Float,1>(input_nc.get_variable<Float>(name, {n_lay}), {n_lay}));
+                else if (dims.size() == 3 && dims.count("lay") && dims.count("y") && dims.count("x"))
+                    aerosol_concs.set_vmr(name, Array<Float,2>(input_nc.get_variable<Float>(name, {n_lay, n_col_y, n_col_x}), {n_col, n_lay}));
+                else
+                    throw std::runtime_error("Illegal dimensions of \"" + name + "\" in input");
+            }
+        }
+        Aerosol_concs_gpu aerosol_concs_gpu(aerosol_concs);
 
         Array_gpu<Float,3> sw_tau, ssa, g;
         Array_gpu<Float,2> toa_src;

@@ -118,7 +118,8 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
     return out
 
 
-def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False, direct=None):
+def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False, direct=None,
+             aerosol_lut=None, delta_aerosol=False):
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
     if fused_gas is None:
         fused_gas = hasattr(be, "gas_optics_sw_fused")
@@ -127,7 +128,7 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
 
     # clear sky: the asymmetry parameter of the gas optics is identically zero; the HIP entry points take "no g array"
     # natively (nothing written by the gas optics, nothing read by the solver)
-    g_zero = bool(fused_gas and cloud_lut is None and getattr(be, "supports_null_g", False))
+    g_zero = bool(fused_gas and cloud_lut is None and aerosol_lut is None and getattr(be, "supports_null_g", False))
     if fused_gas:
         tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol))
         g = None if g_zero else be.empty((ngpt, nlay, ncol))
@@ -149,6 +150,13 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
         if delta_cloud:
             be.delta_scale_2str_k(tc, wc, gc)
         be.inc_2stream_by_2stream_bybnd(tau, ssa, g, tc, wc, gc, kd.band_lims_gpt)
+
+    if aerosol_lut is not None:
+        # /root/reference/src_test/Radiation_solver.cu:794-809
+        ta, wa, ga = be.aerosol_optics(aerosol_lut, [atm.aermr["aermr%02d" % i] for i in range(1, 12)], atm.rh, atm.p_lev)
+        if delta_aerosol:
+            be.delta_scale_2str_k(ta, wa, ga)
+        be.inc_2stream_by_2stream_bybnd(tau, ssa, g, ta, wa, ga, kd.band_lims_gpt)
 
     alb_dir = be.expand_and_transpose(kd.band_lims_gpt, atm.sfc_alb_dir, ngpt)
     alb_dif = be.expand_and_transpose(kd.band_lims_gpt, atm.sfc_alb_dif, ngpt)

@@ -28,7 +28,8 @@ def shard_atmosphere(atm, rank, world):
             else:
                 out[k] = np.ascontiguousarray(v[..., s:e])
         elif isinstance(v, dict):
-            out[k] = {n: np.ascontiguousarray(a[..., s:e]) for n, a in v.items()}
+            # 1-D entries are profiles shared by all columns (aerosol mixing ratios may come that way)
+            out[k] = {n: (np.ascontiguousarray(a[..., s:e]) if a.ndim > 1 else a) for n, a in v.items()}
         else:
             out[k] = v
     out["ncol"] = e - s

@@ -232,6 +232,8 @@ class Atmosphere:
     iwp: np.ndarray = None
     rel: np.ndarray = None
     dei: np.ndarray = None
+    rh: np.ndarray = None  # (nlay, ncol) relative humidity [0..1], aerosol optics only
+    aermr: dict = None     # "aermr01".."aermr11" -> (nlay, ncol) mixing ratio [kg/kg], or an (nlay,) profile
 
     def astype(self, dtype):
         out = {}
@@ -264,7 +266,7 @@ def _rcemip_profile(z):
     return p, q, T
 
 
-def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=False, clouds=False, z_top=70.e3):
+def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=False, clouds=False, z_top=70.e3, aerosols=False):
     """RCEMIP analytic column replicated over ``ncol`` columns with a seeded +-1 K / +-5 % humidity perturbation."""
     rng = np.random.default_rng(seed)
     dz = z_top / nlay
@@ -305,15 +307,61 @@ def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=
         atm["iwp"] = np.where(mask & (atm["t_lay"] < 273.), 10., 0.)
         atm["rel"] = np.where(atm["lwp"] > 0., 12.0, 0.)
         atm["dei"] = np.where(atm["iwp"] > 0., 95.0, 0.)
+    if aerosols:
+        # CAMS-like input of the reference's aerosol test case (test_rte_rrtmgp.cu:303-320): relative humidity spanning every
+        # humidity class (and a little beyond the last bound), 11 mixing ratios decaying with height; two of them given as
+        # plain profiles, the form read_and_set_aer also accepts
+        rng_a = np.random.default_rng(seed + 77)
+        atm["rh"] = np.clip(0.05 + 1.4*np.exp(-z/6.e3)[:, None] * rng_a.uniform(0.6, 1.0, size=(nlay, ncol)), 0., 1.02)
+        scale = [4e-8, 3e-8, 1e-9, 2e-9, 5e-9, 8e-9, 6e-9, 3e-9, 1e-9, 7e-10, 9e-9]
+        atm["aermr"] = {}
+        for i, sc in enumerate(scale, start=1):
+            prof = sc * np.exp(-z/(1.5e3 + 400.*i))
+            if i in (5, 10):
+                atm["aermr"]["aermr%02d" % i] = prof
+            else:
+                atm["aermr"]["aermr%02d" % i] = prof[:, None] * rng_a.uniform(0.5, 1.5, size=(1, ncol)) * rng_a.uniform(0.9, 1.1, size=(nlay, ncol))
     if top_at_1:
-        for k in ("p_lay", "p_lev", "t_lay", "t_lev", "lwp", "iwp", "rel", "dei"):
+        for k in ("p_lay", "p_lev", "t_lay", "t_lev", "lwp", "iwp", "rel", "dei", "rh"):
             if atm.get(k) is not None:
                 atm[k] = np.ascontiguousarray(atm[k][::-1])
         atm["vmr"] = {n: np.ascontiguousarray(a[::-1]) for n, a in atm["vmr"].items()}
+        if atm.get("aermr") is not None:
+            atm["aermr"] = {n: np.ascontiguousarray(a[::-1]) for n, a in atm["aermr"].items()}
     for k, v in list(atm.items()):
         if isinstance(v, np.ndarray):
             atm[k] = np.ascontiguousarray(v)
+    if atm.get("aermr") is not None:
+        atm["aermr"] = {n: np.ascontiguousarray(a) for n, a in atm["aermr"].items()}
     return Atmosphere(**atm)
+
+
+def make_aerosol_lut(nbnd, nhum=12, nphobic=14, nphilic=7):
+    """Synthetic aerosol-optics tables with the shapes and value ranges of data/aerosol_optics.nc as the loader hands them to
+    Aerosol_optics_gpu (/root/reference/src_test/Radiation_solver.cu:366-401): hydrophobic tables stored as numpy
+    (nphobic, nbnd), hydrophilic (nphilic, nhum, nbnd), rh_upper (nhum,) = the upper bounds of the humidity classes."""
+    rh_upper = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.85, 0.9, 0.95, 1.0])[:nhum].copy()
+    rh_upper[-1] = 1.0
+    b = np.arange(nbnd)[None, :]
+    s = np.arange(nphobic)[:, None]
+    lut = dict(rh_upper=rh_upper,
+               mext_phobic=200. * (1. + b)**1.3 * (1. + 0.3*np.sin(1.7*s + 0.2*b)),
+               ssa_phobic=np.clip(0.55 + 0.4*np.cos(0.9*s + 0.35*b)**2, 0., 0.999999),
+               g_phobic=0.35 + 0.45*np.sin(0.5*s + 0.15*b)**2)
+    s3 = np.arange(nphilic)[:, None, None]; h = np.arange(nhum)[None, :, None]; b3 = b[None, :, :]
+    lut.update(mext_philic=120. * (1. + b3)**1.2 * (1. + 0.12*h)**2 * (1. + 0.25*np.cos(1.1*s3 + 0.3*b3)),
+               ssa_philic=np.clip(0.7 + 0.29*np.sin(0.6*s3 + 0.2*h + 0.1*b3)**2, 0., 0.999999),
+               g_philic=0.5 + 0.3*np.cos(0.4*s3 + 0.1*h + 0.2*b3)**2)
+    return {k: np.ascontiguousarray(v) for k, v in lut.items()}
+
+
+def aerosol_lut_from_file_vars(v):
+    """The same dictionary from the variables of a real aerosol_optics.nc (name -> (array, dims), e.g. rrxio.read of the
+    converted file)."""
+    g = lambda n: np.ascontiguousarray(np.asarray(v[n][0], dtype=np.float64))
+    return dict(rh_upper=g("relative_humidity2"),
+                mext_phobic=g("mass_ext_sw_hydrophobic"), ssa_phobic=g("ssa_sw_hydrophobic"), g_phobic=g("asymmetry_sw_hydrophobic"),
+                mext_philic=g("mass_ext_sw_hydrophilic"), ssa_philic=g("ssa_sw_hydrophilic"), g_philic=g("asymmetry_sw_hydrophilic"))
 
 
 def make_cloud_lut(nbnd, kind="lw", nsize_liq=20, nsize_ice=18, seed=99):

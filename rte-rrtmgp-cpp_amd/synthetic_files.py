@@ -144,10 +144,26 @@ def write_input(path, atm, nbnd_lw, nbnd_sw):
     if atm.lwp is not None:
         for k in ("lwp", "iwp", "rel", "dei"):
             v[k] = (f3(getattr(atm, k)), ["lay", "y", "x"])
+    if atm.rh is not None:
+        v["rh"] = (f3(atm.rh), ["lay", "y", "x"])
+        for k, a in atm.aermr.items():
+            v[k] = (f3(a), ["lay", "y", "x"]) if a.ndim == 2 else (a.copy(), ["lay"])
     rrxio.write(path, dims, v)
 
 
-def write_case(directory, atm, kd_lw, kd_sw, lut_lw=None, lut_sw=None):
+def write_aerosol_lut(path, lut):
+    """aerosol_optics.nc with the variables load_and_init_aerosol_optics reads (Radiation_solver.cu:366-401)."""
+    nphobic, nbnd = lut["mext_phobic"].shape
+    nphilic, nhum = lut["mext_philic"].shape[:2]
+    dims = dict(band_sw=nbnd, relative_humidity=nhum, hydrophilic=nphilic, hydrophobic=nphobic)
+    v = {"relative_humidity2": (lut["rh_upper"], ["relative_humidity"])}
+    for file_name, key in (("mass_ext_sw", "mext"), ("ssa_sw", "ssa"), ("asymmetry_sw", "g")):
+        v[file_name + "_hydrophobic"] = (lut[key + "_phobic"], ["hydrophobic", "band_sw"])
+        v[file_name + "_hydrophilic"] = (lut[key + "_philic"], ["hydrophilic", "relative_humidity", "band_sw"])
+    rrxio.write(path, dims, v)
+
+
+def write_case(directory, atm, kd_lw, kd_sw, lut_lw=None, lut_sw=None, lut_aerosol=None):
     """Everything the C++ driver expects in its working directory (file names of the reference's make_links.sh)."""
     os.makedirs(directory, exist_ok=True)
     write_kdist(os.path.join(directory, "coefficients_lw.nc"), kd_lw)
@@ -155,4 +171,6 @@ def write_case(directory, atm, kd_lw, kd_sw, lut_lw=None, lut_sw=None):
     if lut_lw is not None:
         write_cloud_lut(os.path.join(directory, "cloud_coefficients_lw.nc"), lut_lw)
         write_cloud_lut(os.path.join(directory, "cloud_coefficients_sw.nc"), lut_sw)
+    if lut_aerosol is not None:
+        write_aerosol_lut(os.path.join(directory, "aerosol_optics.nc"), lut_aerosol)
     write_input(os.path.join(directory, "rte_rrtmgp_input.nc"), atm, kd_lw.nbnd, kd_sw.nbnd)

@@ -200,3 +200,39 @@ def run_glue_case(be, G, tol):
     got_top = be.to_numpy(fl["flux_dn"])[:, top, :]
     assert rel_err(got_top, half) <= 10*tol, "flux_dn at the top of the domain must equal the incident flux handed in"
     return ck.worst
+
+
+def real_aerosol_lut(tmp_dir):
+    """The tables of the reference tree's data/aerosol_optics.nc (data fixture tests/golden/aerosol_optics.nc), read through
+    the NetCDF-4 backend of the host library (converted to RRXB, then rrxio)."""
+    import ctypes
+    from rte_rrtmgp_cpp_amd import rrxio, synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "rte-rrtmgp-cpp_amd", "lib", "librte_rrtmgp_hip.so"))
+    out = os.path.join(str(tmp_dir), "aerosol_optics.rrxb")
+    assert lib.rrx_host_netcdf_convert(os.path.join(root, "tests", "golden", "aerosol_optics.nc").encode(), out.encode(), b"rrxb") == 0
+    _, v = rrxio.read(out)
+    return synthetic.aerosol_lut_from_file_vars(v)
+
+
+def aerosol_optics_numpy(lut, aermr, rh, plev):
+    """Independent, vectorised evaluation of /root/reference/src/Aerosol_optics.cpp:38-224 (not the oracle's loop nest): used to
+    pin the oracle's restatement. Returns tau, ssa, g (nbnd, nlay, ncol)."""
+    nlay, ncol = rh.shape
+    eps = np.finfo(rh.dtype).eps
+    dpg = np.abs(plev[:-1] - plev[1:]) / rh.dtype.type(9.81)
+    ihum = np.minimum(np.searchsorted(lut["rh_upper"], rh, side="left"), len(lut["rh_upper"]) - 1)     # first bound >= rh
+    species = [(1, "philic", 1), (2, "philic", 2), (3, "philic", 3), (4, "phobic", 1), (5, "phobic", 8), (6, "phobic", 6),
+               (8, "phobic", 10), (7, "philic", 4), (9, "phobic", 11), (10, "phobic", 11), (11, "philic", 5)]
+    nbnd = lut["mext_phobic"].shape[-1]
+    tau = np.zeros((nbnd, nlay, ncol), rh.dtype); ts = np.zeros_like(tau); tsg = np.zeros_like(tau)
+    for im, kind, col in species:
+        m = aermr[im-1]
+        m = np.broadcast_to(m if m.ndim == 2 else m[:, None], (nlay, ncol))
+        if kind == "phobic":
+            tab = lambda n: lut[n + "_phobic"][col-1][:, None, None]
+        else:
+            tab = lambda n: np.moveaxis(lut[n + "_philic"][col-1][ihum], -1, 0)
+        od = (m * dpg)[None] * tab("mext")
+        tau += od; ts += od * tab("ssa"); tsg += od * tab("ssa") * tab("g")
+    return tau, ts / np.maximum(tau, eps), tsg / np.maximum(ts, eps)

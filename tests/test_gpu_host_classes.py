@@ -112,7 +112,7 @@ def test_driver_column_blocks_bands_and_broadband_mode(case, hip_f64):
 def test_driver_error_behaviour(case):
     # same contract as the reference's main(): any exception -> message + exit status 1
     assert run_driver(case["dir"], "--bogus-option") == 1
-    assert run_driver(case["dir"], "--aerosol-optics") == 1
+    assert run_driver(case["dir"], "--aerosol-optics") == 1     # no aerosol_optics.nc / no rh, aermr* in this case's input
     assert run_driver(os.path.dirname(case["dir"])) == 1        # no input file there
 
 
@@ -139,3 +139,64 @@ def test_driver_heating_rates_and_async_mode(case, hip_f64):
         assert cases.rel_err(out[kind + "_heating_rate"], want) <= 1e-12, kind
     # shortwave only ever heats: the net downward flux cannot grow on the way down
     assert np.all(out["sw_heating_rate"] >= -1e-12 * np.abs(out["sw_heating_rate"]).max())
+
+
+@pytest.fixture(scope="module")
+def aerosol_case(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("rrx_aerosol_case"))
+    kl, ks = synthetic.make_kdist("lw", **KW), synthetic.make_kdist("sw", **KW)
+    atm = synthetic.make_atmosphere(45, 60, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], clouds=True, aerosols=True, seed=8)
+    ll, ls = synthetic.make_cloud_lut(KW["nbnd"], "lw"), synthetic.make_cloud_lut(KW["nbnd"], "sw")
+    la = synthetic.make_aerosol_lut(KW["nbnd"])
+    synthetic_files.write_case(d, atm, kl, ks, ll, ls, la)
+    return dict(dir=d, kl=kl, ks=ks, atm=atm, ll=ll, ls=ls, la=la)
+
+
+@pytest.mark.parametrize("delta", [False, True])
+def test_driver_aerosol_optics_matches_pipeline_and_oracle(aerosol_case, delta, hip_f64, oracle_f64):
+    """--aerosol-optics [--delta-aerosol] through Aerosol_optics_gpu / Radiation_solver_shortwave, in column
+    blocks of 7 (per-column mixing ratios are subset per block, profiles shared), against the launcher pipeline and the oracle."""
+    c = aerosol_case
+    flags = ["--aerosol-optics", "--cloud-optics", "--output-optical"] + (["--delta-aerosol"] if delta else [])
+    assert run_driver(c["dir"], *flags, env={"RRX_COL_BLOCK": "7"}) == 0
+    _, out = read_output(c["dir"])
+    res = {}
+    for be in (hip_f64, oracle_f64):
+        r = pipeline.solve_sw(be, be.upload_kdist(c["ks"]), pipeline.upload_atmosphere(be, c["atm"]), cloud_lut=be.upload_lut(c["ls"]),
+                              delta_cloud=True, aerosol_lut=be.upload_lut(c["la"]), delta_aerosol=delta, keep=True)
+        res[be] = dict(sw_flux_up=r["flux_up"], sw_flux_dn=r["flux_dn"], sw_flux_dn_dir=r["flux_dn_dir"], sw_flux_net=r["flux_net"],
+                       sw_tau=r["tau"], ssa=r["ssa"], g=r["g"])
+        res[be] = {k: be.to_numpy(v) for k, v in res[be].items()}
+    for k in res[hip_f64]:
+        assert cases.rel_err(out[k], res[hip_f64][k]) <= 1e-11, f"C++ classes vs launcher pipeline: {k}"
+        assert cases.rel_err(out[k], res[oracle_f64][k]) <= (1e-7 if k.startswith("sw_flux") else 1e-9), f"C++ classes vs CPU oracle: {k}"
+    # single block = same numbers
+    assert run_driver(c["dir"], *flags) == 0
+    _, one = read_output(c["dir"])
+    for k in res[hip_f64]:
+        assert cases.rel_err(one[k], out[k]) <= 1e-12, k
+
+
+def test_driver_on_netcdf4_files(aerosol_case, tmp_path):
+    """the same case with every input file in NetCDF-4 (HDF5) form and NetCDF-4 output, converted back for the
+    comparison: identical to the run on RRXB containers bit for bit."""
+    c = aerosol_case
+    flags = ["--aerosol-optics", "--cloud-optics", "--output-bnd-fluxes"]
+    assert run_driver(c["dir"], *flags) == 0
+    _, ref = read_output(c["dir"])
+    lib = ctypes.CDLL(HOSTLIB)
+    d = str(tmp_path)
+    for f in os.listdir(c["dir"]):
+        if f != "rte_rrtmgp_output.nc":
+            assert lib.rrx_host_netcdf_convert(os.path.join(c["dir"], f).encode(), os.path.join(d, f).encode(), b"netcdf4") == 0
+            with open(os.path.join(d, f), "rb") as fh:
+                assert fh.read(4) == b"\x89HDF"
+    assert run_driver(d, *flags, env={"RRX_OUTPUT_FORMAT": "netcdf4"}) == 0
+    with open(os.path.join(d, "rte_rrtmgp_output.nc"), "rb") as fh:
+        assert fh.read(4) == b"\x89HDF"
+    assert lib.rrx_host_netcdf_convert(os.path.join(d, "rte_rrtmgp_output.nc").encode(), os.path.join(d, "out.rrxb").encode(), b"rrxb") == 0
+    dims, v = rrxio.read(os.path.join(d, "out.rrxb"))
+    out = {k: a[0].squeeze(axis=-2) if a[0].ndim >= 3 else a[0] for k, a in v.items()}
+    assert set(out) == set(ref)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k

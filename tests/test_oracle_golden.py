@@ -39,3 +39,21 @@ def test_golden_set_is_complete():
         for top in (0, 1):
             assert f"chain_{tag}_top{top}.npz" in names and f"random_{tag}_top{top}.npz" in names
             assert f"glue_{tag}_top{top}.npz" in names
+
+
+@pytest.mark.parametrize("top_at_1", [False, True])
+@pytest.mark.parametrize("table", ["real", "synthetic"])
+def test_oracle_aerosol_optics_matches_independent_numpy_evaluation(table, top_at_1, tmp_path, oracle_f64):
+    """SURVEY 8(f3). The reference holds no golden vectors for aerosol optics, so the oracle's restatement of
+    src/Aerosol_optics.cpp:24-224 is pinned against an independent vectorised evaluation of the same formulas, on the tables
+    of the reference tree's data/aerosol_optics.nc and on synthetic tables with another band count."""
+    from rte_rrtmgp_cpp_amd import synthetic
+    lut = cases.real_aerosol_lut(tmp_path) if table == "real" else synthetic.make_aerosol_lut(5)
+    assert lut["mext_phobic"].shape == ((14, 14) if table == "real" else (14, 5)) and lut["rh_upper"][-1] == 1.0
+    atm = synthetic.make_atmosphere(23, 37, aerosols=True, top_at_1=top_at_1, seed=11)
+    aermr = [atm.aermr["aermr%02d" % i] for i in range(1, 12)]
+    assert sorted(a.ndim for a in aermr) == [1, 1] + [2]*9 and atm.rh.max() > 1.0 and atm.rh.min() < 0.3
+    tau, ssa, g = oracle_f64.aerosol_optics(lut, aermr, atm.rh, atm.p_lev)
+    t2, s2, g2 = cases.aerosol_optics_numpy(lut, aermr, atm.rh, atm.p_lev)
+    assert tau.min() > 0 and 0 < ssa.min() and ssa.max() < 1 and 0 < g.min() and g.max() < 1
+    assert cases.rel_err(tau, t2) <= 1e-14 and cases.rel_err(ssa, s2) <= 1e-14 and cases.rel_err(g, g2) <= 1e-14
