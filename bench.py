@@ -27,9 +27,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic words per (column, g-point) at nlay layers -- SURVEY.md section 8(d), DESIGN.md section 5
-def algo_words(nlay, ngpt, broadband, g_zero):
+def algo_words(nlay, ngpt, nbnd, broadband, g_zero, lite):
     nlev = nlay + 1
     nsw = 2 if g_zero else 3        # clear sky: the all-zero asymmetry array is neither written nor read
+    if broadband and lite:
+        # "Planck-lite" chain: the gas optics writes tau and the Planck fraction per g-point plus the band Planck functions
+        # B_lay, B_lev (nbnd/ngpt of a g-point array each); the solver forms the sources from them on chip
+        bands = (nlay + nlev) * nbnd / ngpt
+        return dict(
+            lw_gas_optics=2*nlay + bands + 2,                # tau, pfrac, B_lay, B_lev, sfc_src(+jac)
+            lw_planck=0,
+            lw_solver=2*nlay + bands + 1 + 2 + 2*nlev/ngpt,  # tau, pfrac, B, secant, sfc_emis + sfc_src, flux sums once
+            lw_reduce=0,
+            sw_gas_optics=nsw*nlay + 1,
+            sw_solver=nsw*nlay + 3 + 3*nlev/ngpt,
+            sw_reduce=0)
     if broadband:       # fused form: the solvers keep the g-point sums on chip and store (ncol, nlev) arrays once
         return dict(
             lw_gas_optics=nlay,
@@ -49,21 +61,44 @@ def algo_words(nlay, ngpt, broadband, g_zero):
         sw_reduce=3*nlev)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# vector-ALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction (fp64 or fp32, non-packed) per SIMD per 4 cycles at the
+# 2.4 GHz peak engine clock (MI355X_MICROARCH.md: 78.6 TFLOP/s fp64 vector = this rate x 64 lanes x 2 flops)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+
+STAGE_KERNEL = {"lw_solver": ("lw_noscat_bb_kernel", "lw_noscat_scan_kernel"), "sw_solver": ("sw_2stream_scan_kernel",),
+                "lw_planck": ("planck_source_kernel",)}
+
+
+def _pmc_entry(stage, args):
+    """Entry of the committed rocprofv3 counter summary of the SAME workload for the stage's kernel (profiles/pmc_traffic.json,
+    written by tools/profile_round.sh + tools/pmc_summary.py from separate --pmc passes), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path) or stage not in STAGE_KERNEL:
+        return None
+    tag = f"{args.dtype}|{'broadband' if args.broadband else 'per-gpoint'}|{args.ncol}x{args.nlay}x{args.ngpt}|"
+    best = None
+    for k, v in json.load(open(path)).items():
+        if any(k.startswith(tag + kern) for kern in STAGE_KERNEL[stage]) and "fetch_bytes" in v and "write_bytes" in v:
+            if best is None or v["fetch_bytes"] > best["fetch_bytes"]:
+                best = v
+    return best
 
 
 def pmc_traffic(stage, args):
-    """HBM-side bytes per launch of the stage's kernel from the committed rocprofv3 counter summary of the SAME workload
-    (profiles/pmc_traffic.json, written by tools/profile_round.sh + tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no matching entry exists."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM-side bytes per launch (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE)."""
+    v = _pmc_entry(stage, args)
+    return None if v is None else int(v["fetch_bytes"] + v["write_bytes"])
+
+
+def valu_roofline(stage, args, ms):
+    """Second roof of a solver kernel: vector-ALU issue. Wave-level VALU instructions per launch come from the committed
+    SQ_INSTS_VALU pass of the same workload (a property of the compiled kernel and the shape); the time is measured live."""
+    v = _pmc_entry(stage, args)
+    if v is None or "insts_valu" not in v:
         return None
-    tag = f"{args.dtype}|{'broadband' if args.broadband else 'per-gpoint'}|{args.ncol}x{args.nlay}x{args.ngpt}|"
-    kern = {"lw_solver": "lw_noscat_scan_kernel", "sw_solver": "sw_2stream_scan_kernel", "lw_planck": "planck_source_kernel"}[stage]
-    for k, v in json.load(open(path)).items():
-        if k.startswith(tag + kern) and "fetch_bytes" in v and "write_bytes" in v:
-            return int(v["fetch_bytes"] + v["write_bytes"])
-    return None
+    ginst = v["insts_valu"] / (ms*1e-3) / 1e9
+    return {"bound": "valu", "kernel": stage, "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+            "frac": round(ginst / VALU_PEAK_GINST, 4), "valu_wave_instructions_per_launch": int(v["insts_valu"])}
 
 
 def cpu_baseline(args, kd_lw0, kd_sw0, be=None):
@@ -243,13 +278,13 @@ def main():
     if rank == 0:
         S = np_dtype().itemsize
         ms = solver.stage_ms()
-        words = algo_words(args.nlay, args.ngpt, args.broadband, solver.g_zero and args.broadband)
+        words = algo_words(args.nlay, args.ngpt, nbnd, args.broadband, solver.g_zero and args.broadband, solver.lite)
         units = ncol_local * args.ngpt
         kernels = {}
         for st, w in words.items():
             gbs = w * units * S / (max(ms[st], 1e-6)*1e-3) / 1e9
             kernels[st] = dict(ms=round(ms[st], 4), algo_GB=round(w*units*S/1e9, 4), GBs=round(gbs, 1), frac=round(gbs/HBM_PEAK_GBS, 4))
-        single = {k: v for k, v in kernels.items() if k in ("lw_solver", "sw_solver", "lw_planck")}   # single-launch stages
+        single = {k: v for k, v in kernels.items() if k in STAGE_KERNEL and v["ms"] > 0}   # single-launch stages
         dom = max(single, key=lambda k: single[k]["ms"])
         finite = bool(torch.isfinite(solver.fluxes).all().item())
         out = {
@@ -269,6 +304,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac"], "traffic": pmc_traffic(dom, args),
                          "algorithmic_bytes_per_launch": int(words[dom]*units*S), "avg_launch_ms": kernels[dom]["ms"]},
+            "roofline_valu": valu_roofline(dom, args, kernels[dom]["ms"]),
             "stages": kernels,
             "finite": finite,
         }

@@ -44,6 +44,23 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/rrx_hip.h but not exported: {missing}"
 
 
+def test_rccl_library_exports_every_declared_symbol_and_splits_columns_like_the_python_side():
+    """include/rrx_rccl.h (the all-gather below Python): every declared symbol is exported; rrx_column_range is the rule of
+    sharding.column_range (no GPU or communicator needed for either)."""
+    from rte_rrtmgp_cpp_amd import sharding
+    text = open(os.path.join(ROOT, "include", "rrx_rccl.h")).read()
+    names = sorted(set(re.findall(r"\b(rrx_\w+)\s*\(", text)))
+    assert "rrx_allgather_fluxes_f64" in names and "rrx_comm_create" in names
+    lib = ctypes.CDLL(os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "librrx_rccl.so"))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    s, e = ctypes.c_int(), ctypes.c_int()
+    for world, ntot in ((1, 5), (2, 45), (3, 16384), (8, 16384), (8, 16389), (6, 6)):
+        for r in range(world):
+            lib.rrx_column_range(r, world, ntot, ctypes.byref(s), ctypes.byref(e))
+            assert (s.value, e.value) == tuple(sharding.column_range(r, world, ntot))
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     import numpy as np

@@ -605,3 +605,27 @@ def test_aerosol_optics_and_aerosol_sw_solve_match_oracle(dt, top_at_1, tmp_path
     atm = pipeline.upload_atmosphere(hip, atm0)
     r0 = pipeline.solve_sw(hip, hip.upload_kdist(kd0), atm, cloud_lut=hip.upload_lut(cl), delta_cloud=True)
     assert cases.rel_err(hip.to_numpy(r0["flux_dn_dir"]), out[hip]["flux_dn_dir"]) > 1e-3
+
+
+def test_rccl_allgather_fluxes_c_abi(hip_f64):
+    """include/rrx_rccl.h: (i) the pad / place kernels reproduce a column-sharded array for several world sizes, including
+    uneven splits (layout check on one device); (ii) a real communicator of one rank: rrx_allgather_fluxes is the identity."""
+    import ctypes
+    import torch
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rte-rrtmgp-cpp_amd", "lib", "librrx_rccl.so"))
+    lib.rrx_rccl_last_error.restype = ctypes.c_char_p
+    for world, nrows, ntot in ((1, 7, 33), (2, 7*5, 45), (3, 11, 100), (8, 7*141, 2053), (6, 4, 6)):
+        assert lib.rrx_rccl_selftest_layout(world, nrows, ntot) == 0, (world, nrows, ntot, lib.rrx_rccl_last_error())
+    uid = ctypes.create_string_buffer(128)
+    assert lib.rrx_comm_get_unique_id(uid) == 0, lib.rrx_rccl_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.rrx_comm_create(1, 0, uid, ctypes.byref(comm)) == 0, lib.rrx_rccl_last_error()
+    local = torch.arange(7*141*50, dtype=torch.float64, device="cuda:0").reshape(7*141, 50) * 0.5
+    out = torch.zeros_like(local); scratch = torch.empty(2*local.numel(), dtype=torch.float64, device="cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.rrx_allgather_fluxes_f64(comm, 7*141, 50, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                      ctypes.c_void_p(scratch.data_ptr()), st)
+    assert rc == 0, lib.rrx_rccl_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(out, local)
+    assert lib.rrx_comm_destroy(comm) == 0

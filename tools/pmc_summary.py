@@ -36,4 +36,6 @@ if a.json:
             e["fetch_bytes"] = 2.0 * 1024.0 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         if "WRITE_SIZE" in cs:
             e["write_bytes"] = 1024.0 * sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        if "SQ_INSTS_VALU" in cs:          # wave-level VALU instructions per launch (bench.py: roofline_valu)
+            e["insts_valu"] = sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"])
     json.dump(out, open(a.json, "w"), indent=1, sort_keys=True)

@@ -21,16 +21,16 @@ for mode in broadband per-gpoint; do
   find $OUT/kt_$mode -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_f64_$mode.csv \;
   find $OUT/kt_$mode -name "*kernel_trace.csv" -delete
   echo "kernel trace $mode done"
-  for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${mode}_$c -o pmc -- python3 $REPO/bench.py --flux-mode $mode --cpu-cols 0 --steps 3 --warmup 1 > $OUT/pmc_${mode}_$c.log 2>&1 || echo "pmc $mode $c FAILED"
+  for c in FETCH_SIZE WRITE_SIZE SQ; do
+    [ $c = SQ ] && CTRS="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" || CTRS=$c
+    timeout -k 10 400 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_${mode}_$c -o pmc -- python3 $REPO/bench.py --flux-mode $mode --cpu-cols 0 --steps 3 --warmup 1 > $OUT/pmc_${mode}_$c.log 2>&1 || echo "pmc $mode $c FAILED"
     echo "pmc $mode $c done"
   done
-  python3 $REPO/tools/pmc_summary.py $OUT --filter scan_kernel > /dev/null
 done
 cd $REPO
 for mode in broadband per-gpoint; do
   mkdir -p $OUT/sel_$mode; rm -rf $OUT/sel_$mode/*
-  for c in FETCH_SIZE WRITE_SIZE; do cp -r $OUT/pmc_${mode}_$c $OUT/sel_$mode/; done
+  for c in FETCH_SIZE WRITE_SIZE SQ; do cp -r $OUT/pmc_${mode}_$c $OUT/sel_$mode/; done
   python3 tools/pmc_summary.py $OUT/sel_$mode --json $OUT/${TAG}_pmc_traffic.json --tag "f64|$mode|16384x140x256" > $OUT/${TAG}_pmc_${mode}.txt
   rm -rf $OUT/sel_$mode
 done
