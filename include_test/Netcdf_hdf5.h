@@ -62,7 +62,7 @@ namespace rrx_h5
         RRX_H5_FN(H5Screate_simple) RRX_H5_FN(H5Screate) RRX_H5_FN(H5Sclose)
         RRX_H5_FN(H5Sget_simple_extent_ndims) RRX_H5_FN(H5Sget_simple_extent_dims)
         RRX_H5_FN(H5Tget_class) RRX_H5_FN(H5Tget_size) RRX_H5_FN(H5Tcopy) RRX_H5_FN(H5Tset_size) RRX_H5_FN(H5Tclose)
-        RRX_H5_FN(H5Tvlen_create) RRX_H5_FN(H5Tset_strpad)
+        RRX_H5_FN(H5Tvlen_create) RRX_H5_FN(H5Tset_strpad) RRX_H5_FN(H5Tis_variable_str) RRX_H5_FN(H5free_memory)
         RRX_H5_FN(H5Aexists) RRX_H5_FN(H5Aopen) RRX_H5_FN(H5Aread) RRX_H5_FN(H5Aclose) RRX_H5_FN(H5Aget_type) RRX_H5_FN(H5Aget_space)
         RRX_H5_FN(H5Acreate2) RRX_H5_FN(H5Awrite)
         RRX_H5_FN(H5Rdereference2) RRX_H5_FN(H5Rcreate) RRX_H5_FN(H5Iget_name) RRX_H5_FN(H5Oclose)
@@ -90,7 +90,7 @@ namespace rrx_h5
         RRX_H5_LOAD(H5Screate_simple) RRX_H5_LOAD(H5Screate) RRX_H5_LOAD(H5Sclose)
         RRX_H5_LOAD(H5Sget_simple_extent_ndims) RRX_H5_LOAD(H5Sget_simple_extent_dims)
         RRX_H5_LOAD(H5Tget_class) RRX_H5_LOAD(H5Tget_size) RRX_H5_LOAD(H5Tcopy) RRX_H5_LOAD(H5Tset_size) RRX_H5_LOAD(H5Tclose)
-        RRX_H5_LOAD(H5Tvlen_create) RRX_H5_LOAD(H5Tset_strpad)
+        RRX_H5_LOAD(H5Tvlen_create) RRX_H5_LOAD(H5Tset_strpad) RRX_H5_LOAD(H5Tis_variable_str) RRX_H5_LOAD(H5free_memory)
         RRX_H5_LOAD(H5Aexists) RRX_H5_LOAD(H5Aopen) RRX_H5_LOAD(H5Aread) RRX_H5_LOAD(H5Aclose) RRX_H5_LOAD(H5Aget_type) RRX_H5_LOAD(H5Aget_space)
         RRX_H5_LOAD(H5Acreate2) RRX_H5_LOAD(H5Awrite)
         RRX_H5_LOAD(H5Rdereference2) RRX_H5_LOAD(H5Rcreate) RRX_H5_LOAD(H5Iget_name) RRX_H5_LOAD(H5Oclose)
@@ -123,7 +123,15 @@ namespace rrx_h5
         if (at < 0) return std::string();
         const hid_t ft = a.H5Aget_type(at);
         std::string out;
-        if (a.H5Tget_class(ft) == H5T_STRING)
+        if (a.H5Tget_class(ft) == H5T_STRING && a.H5Tis_variable_str(ft) > 0)
+        {
+            // NC_STRING attribute (netCDF4-python writes these for non-ASCII or when asked to): one variable-length string
+            char* p = nullptr;
+            const hid_t mt = a.H5Tcopy(a.t_c_s1); a.H5Tset_size(mt, H5T_VARIABLE);
+            if (a.H5Aread(at, mt, &p) >= 0 && p) { out = p; a.H5free_memory(p); }
+            a.H5Tclose(mt);
+        }
+        else if (a.H5Tget_class(ft) == H5T_STRING)
         {
             const size_t n = a.H5Tget_size(ft);
             if (n > 0 && n < (1u << 20))
@@ -280,6 +288,28 @@ namespace rrx_h5
         a.H5Sclose(s); a.H5Tclose(t);
     }
 
+    // String attribute of a variable (or of the file: var empty) -- what the RFMIP acceptance script needs ("units" scale factors);
+    // the class API of the reference has no attribute access, so this stays outside Netcdf_handle.
+    inline std::string get_string_attr(const std::string& path, const std::string& var, const std::string& attr)
+    {
+        Api& a = api();
+        const hid_t file = a.H5Fopen(path.c_str(), 0u /* H5F_ACC_RDONLY */, H5P_DEFAULT);
+        if (file < 0) throw std::runtime_error("cannot open HDF5 file " + path);
+        std::string out;
+        if (var.empty()) out = read_string_attr(a, file, attr.c_str());
+        else
+        {
+            const hid_t ds = a.H5Dopen2(file, var.c_str(), H5P_DEFAULT);
+            if (ds < 0) { a.H5Fclose(file); throw std::runtime_error("variable " + var + " not found in " + path); }
+            out = read_string_attr(a, ds, attr.c_str());
+            a.H5Dclose(ds);
+        }
+        a.H5Fclose(file);
+        return out;
+    }
+
+    inline void put_string_attr(const std::string& path, const std::string& var, const std::string& attr, const std::string& value);
+
     // Writes the in-memory model as a NetCDF-4 file: one dimension-scale dataset per dimension, one dataset per variable
     // with its DIMENSION_LIST.
     inline void write_file(const std::string& path, const std::map<std::string, int64_t>& dims, const std::vector<std::string>& dim_order,
@@ -359,6 +389,17 @@ namespace rrx_h5
             a.H5Dclose(ds); a.H5Sclose(sp);
         }
         a.H5Fclose(file);
+    }
+
+    inline void put_string_attr(const std::string& path, const std::string& var, const std::string& attr, const std::string& value)
+    {
+        Api& a = api();
+        const hid_t file = a.H5Fopen(path.c_str(), 1u /* H5F_ACC_RDWR */, H5P_DEFAULT);
+        if (file < 0) throw std::runtime_error("cannot open HDF5 file " + path + " for writing");
+        const hid_t ds = a.H5Dopen2(file, var.c_str(), H5P_DEFAULT);
+        if (ds < 0) { a.H5Fclose(file); throw std::runtime_error("variable " + var + " not found in " + path); }
+        write_string_attr(a, ds, attr.c_str(), value);
+        a.H5Dclose(ds); a.H5Fclose(file);
     }
 }
 #else

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <vector>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include "Array.h"
 #include "Optical_props.h"
@@ -73,6 +74,33 @@ int rrx_host_netcdf_convert(const char* in_path, const char* out_path, const cha
         return 0;
     }
     catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_convert: %s\n", e.what()); return 1; }
+}
+
+// String attribute of a variable of a NetCDF-4 file (e.g. "units"); returns the length, -1 when absent or on error.
+int rrx_host_netcdf_get_attr(const char* path, const char* var, const char* attr, char* buf, int buflen)
+{
+#ifdef RRX_HAVE_HDF5_HEADERS
+    try
+    {
+        const std::string v = rrx_h5::get_string_attr(path, var, attr);
+        if (v.empty() || int(v.size()) >= buflen) return -1;
+        std::memcpy(buf, v.c_str(), v.size() + 1);
+        return int(v.size());
+    }
+    catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_get_attr: %s\n", e.what()); return -1; }
+#else
+    (void)path; (void)var; (void)attr; (void)buf; (void)buflen; return -1;
+#endif
+}
+
+int rrx_host_netcdf_put_attr(const char* path, const char* var, const char* attr, const char* value)
+{
+#ifdef RRX_HAVE_HDF5_HEADERS
+    try { rrx_h5::put_string_attr(path, var, attr, value); return 0; }
+    catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_put_attr: %s\n", e.what()); return 1; }
+#else
+    (void)path; (void)var; (void)attr; (void)value; return 1;
+#endif
 }
 
 // NetCDF-4 round trip through the HDF5 backend: dimensions, dimension order of each variable, f64 / f32 / i32 / char data,

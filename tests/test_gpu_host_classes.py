@@ -200,3 +200,81 @@ def test_driver_on_netcdf4_files(aerosol_case, tmp_path):
     assert set(out) == set(ref)
     for k in ref:
         assert np.array_equal(out[k], ref[k]), k
+
+
+def test_acceptance_script_on_a_stand_in_data_tree(tmp_path, oracle_f64):
+    """tools/acceptance.py (the reference's all-sky and RFMIP acceptance runs around this build's driver) end to
+    end on a stand-in rrtmgp-data tree: NetCDF-4 coefficient files under the real names, an RFMIP-style input file with `units`
+    attributes, and "reference" fluxes computed by the CPU oracle on the same problems. Thresholds are the reference's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("acceptance", os.path.join(ROOT, "tools", "acceptance.py"))
+    acc = importlib.util.module_from_spec(spec); spec.loader.exec_module(acc)
+    lib = ctypes.CDLL(HOSTLIB)
+    data, tmp = str(tmp_path / "rrtmgp-data"), str(tmp_path / "tmp")
+    os.makedirs(tmp)
+    for sub in ("", acc.ALLSKY_REF, acc.RFMIP_REF, os.path.dirname(acc.RFMIP_IN)):
+        os.makedirs(os.path.join(data, sub), exist_ok=True)
+
+    def to_nc4(write, *args, name):
+        write(os.path.join(tmp, "x.rrxb"), *args)
+        assert lib.rrx_host_netcdf_convert(os.path.join(tmp, "x.rrxb").encode(), os.path.join(data, name).encode(), b"netcdf4") == 0
+
+    kl, ks = synthetic.make_kdist("lw", **KW), synthetic.make_kdist("sw", **KW)
+    ll, ls = synthetic.make_cloud_lut(KW["nbnd"], "lw"), synthetic.make_cloud_lut(KW["nbnd"], "sw")
+    to_nc4(synthetic_files.write_kdist, kl, name=acc.GAS_LW); to_nc4(synthetic_files.write_kdist, ks, name=acc.GAS_SW)
+    to_nc4(synthetic_files.write_cloud_lut, ll, name=acc.CLD_LW); to_nc4(synthetic_files.write_cloud_lut, ls, name=acc.CLD_SW)
+    be = oracle_f64
+    gases = list(kl.gas_names)
+
+    def oracle_fluxes(dims, v, clouds):
+        atm = pipeline.upload_atmosphere(be, acc.atmosphere_from_input(dims, v, gases, tsi_ref=float(ks.solar_source.sum())))
+        lw = pipeline.solve_lw(be, be.upload_kdist(kl), atm, cloud_lut=be.upload_lut(ll) if clouds else None)
+        sw = pipeline.solve_sw(be, be.upload_kdist(ks), atm, cloud_lut=be.upload_lut(ls) if clouds else None, delta_cloud=True)
+        return {**{"lw_" + k: be.to_numpy(a) for k, a in lw.items()}, **{"sw_" + k: be.to_numpy(a) for k, a in sw.items()}}
+
+    # all-sky reference files (lev, col), written as NetCDF-4
+    dims, v = acc.allsky_input(KW["nbnd"], KW["nbnd"])
+    f = oracle_fluxes(dims, v, True)
+    d2 = dict(lev=dims["lev"], col=dims["x"])
+    to_nc4(rrxio.write, d2, {"lw_flux_up": (f["lw_flux_up"], ["lev", "col"]), "lw_flux_dn": (f["lw_flux_dn"], ["lev", "col"])},
+           name=os.path.join(acc.ALLSKY_REF, "rrtmgp-allsky-lw-no-aerosols.nc"))
+    to_nc4(rrxio.write, d2, {"sw_flux_up": (f["sw_flux_up"], ["lev", "col"]), "sw_flux_dn": (f["sw_flux_dn"], ["lev", "col"]),
+                             "sw_flux_dir": (f["sw_flux_dn_dir"], ["lev", "col"])},
+           name=os.path.join(acc.ALLSKY_REF, "rrtmgp-allsky-sw-no-aerosols.nc"))
+
+    # RFMIP-style input: 2 experiments x 5 sites x 20 layers, top first, concentrations scaled by their `units`
+    n_expt, n_site, n_lay = 2, 5, 20
+    base = synthetic.make_atmosphere(n_site, n_lay, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], top_at_1=True, seed=21)
+    rd = dict(expt=n_expt, site=n_site, layer=n_lay, level=n_lay+1)
+    e = np.arange(n_expt)[:, None, None]
+    rv = {"pres_layer": (base.p_lay.T.copy(), ["site", "layer"]), "pres_level": (base.p_lev.T.copy(), ["site", "level"]),
+          "temp_layer": (base.t_lay.T[None] + 2.0*e, ["expt", "site", "layer"]), "temp_level": (base.t_lev.T[None] + 2.0*e, ["expt", "site", "level"]),
+          "surface_temperature": (base.t_sfc[None] + 2.0*e[:, :, 0], ["expt", "site"]),
+          "surface_emissivity": (np.linspace(0.95, 0.99, n_site), ["site"]), "surface_albedo": (np.linspace(0.05, 0.3, n_site), ["site"]),
+          "solar_zenith_angle": (np.linspace(10., 85., n_site), ["site"]), "total_solar_irradiance": (np.linspace(1300., 1400., n_site), ["site"]),
+          "water_vapor": (base.vmr["h2o"].T[None] * (1. + 0.1*e) * 1e3, ["expt", "site", "layer"]),
+          "ozone": (base.vmr["o3"].T[None] * (1. + 0.0*e) * 1e6, ["expt", "site", "layer"])}
+    units = {"water_vapor": "1e-3", "ozone": "1e-6"}
+    for gas, name in acc.RFMIP_GASES:
+        if gas == "co":
+            continue        # the stand-in k-distribution file lists co as a contributor with junk coefficients (absent-gas test)
+        ref_v = float(base.vmr[gas][0, 0]) if gas in base.vmr else 1e-9
+        rv[name] = (ref_v * 1e6 * (1. + 0.5*np.arange(n_expt)), ["expt"]); units[name] = "1e-6"
+    to_nc4(rrxio.write, rd, rv, name=acc.RFMIP_IN)
+    for name, u in units.items():
+        assert lib.rrx_host_netcdf_put_attr(os.path.join(data, acc.RFMIP_IN).encode(), name.encode(), b"units", u.encode()) == 0
+    assert acc.nc_attr(os.path.join(data, acc.RFMIP_IN), "methane_GM", "units") == "1e-6"
+    got = {k: [] for k in ("rld", "rlu", "rsd", "rsu")}
+    for expt, dims, v in acc.rfmip_inputs(data, tmp, KW["nbnd"], KW["nbnd"]):
+        assert abs(float(v["vmr_co2"][0]) - 348.e-6*(1. + 0.5*expt)) < 1e-12 and v["p_lay"][0].shape == (n_lay, 1, n_site)
+        f = oracle_fluxes(dims, v, False)
+        for rf, name in (("rld", "lw_flux_dn"), ("rlu", "lw_flux_up"), ("rsd", "sw_flux_dn"), ("rsu", "sw_flux_up")):
+            got[rf].append(f[name].T)
+    for rf, arrs in got.items():
+        to_nc4(rrxio.write, rd, {rf: (np.stack(arrs), ["expt", "site", "level"])},
+               name=os.path.join(acc.RFMIP_REF, rf + "_Efx_RTE-RRTMGP-181204_rad-irf_r1i1p1f1_gn.nc"))
+
+    results = acc.case_allsky(data, str(tmp_path / "work_allsky")) + acc.case_rfmip(data, str(tmp_path / "work_rfmip"))
+    assert len(results) == 9
+    for name, diff, thr in results:
+        assert diff <= min(thr, 1e-6), (name, diff)
