@@ -4,8 +4,18 @@
 // --timings), download, write rte_rrtmgp_output. Files are RRXB containers (include_test/Netcdf_interface.h), extension .nc
 // kept so that run scripts need no change; two extra options: --broadband-solvers (on by default: the solvers sum the g-points
 // themselves; --no-broadband-solvers restores per-g-point fluxes + sum_broadband) and the environment variable RRX_COL_BLOCK (columns per block, default 16384).
+// --ngpus=N: the process becomes the launcher of N ranks of itself, one per GPU; rank r solves the contiguous column
+// range rrx_column_range(r, N, ncol), the broadband (and optional band / optical) outputs are all-gathered over RCCL
+// (include/rrx_rccl.h, librrx_rccl.so loaded on demand) and rank 0 writes the output file.
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <functional>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <vector>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -16,9 +26,157 @@
 #include "Array.h"
 #include "Gas_concs.h"
 #include "Radiation_solver.h"
+#include "rrx_rccl.h"
+
+extern char** environ;
 
 namespace
 {
+    // ---- multi-GPU context of one rank: the RCCL library is loaded only when there is more than one rank
+    struct Ranks
+    {
+        int world = 1, rank = 0;
+        void* lib = nullptr;
+        void* comm = nullptr;
+        decltype(&rrx_comm_get_unique_id) get_unique_id = nullptr;
+        decltype(&rrx_comm_id_to_file) id_to_file = nullptr;
+        decltype(&rrx_comm_id_from_file) id_from_file = nullptr;
+        decltype(&rrx_comm_create) create = nullptr;
+        decltype(&rrx_comm_destroy) destroy = nullptr;
+        decltype(&rrx_rccl_last_error) last_error = nullptr;
+#ifdef RTE_USE_SP
+        decltype(&rrx_allgather_fluxes_f32) allgather = nullptr;
+#else
+        decltype(&rrx_allgather_fluxes_f64) allgather = nullptr;
+#endif
+        int col_s = 0, col_e = 0;            // this rank's columns [col_s, col_e), 0-based
+
+        static std::string library_dir()
+        {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<void*>(&library_dir), &info) == 0 || !info.dli_fname) return ".";
+            const std::string p(info.dli_fname);
+            const size_t k = p.rfind('/');
+            return k == std::string::npos ? "." : p.substr(0, k);
+        }
+
+        void check(const int rc, const char* what) const
+        {
+            if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (last_error ? last_error() : "?"));
+        }
+
+        void init(const int world_, const int rank_, const int n_col_total)
+        {
+            world = world_; rank = rank_;
+            col_s = 0; col_e = n_col_total;
+            if (world == 1) return;
+            if (n_col_total < world) throw std::runtime_error("fewer columns than GPUs");
+            const std::string path = library_dir() + "/librrx_rccl.so";
+            lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!lib) throw std::runtime_error("cannot load " + path + ": " + dlerror());
+            auto sym = [&](const char* n) { void* q = dlsym(lib, n); if (!q) throw std::runtime_error(std::string("librrx_rccl: missing ") + n); return q; };
+            get_unique_id = reinterpret_cast<decltype(get_unique_id)>(sym("rrx_comm_get_unique_id"));
+            id_to_file = reinterpret_cast<decltype(id_to_file)>(sym("rrx_comm_id_to_file"));
+            id_from_file = reinterpret_cast<decltype(id_from_file)>(sym("rrx_comm_id_from_file"));
+            create = reinterpret_cast<decltype(create)>(sym("rrx_comm_create"));
+            destroy = reinterpret_cast<decltype(destroy)>(sym("rrx_comm_destroy"));
+            last_error = reinterpret_cast<decltype(last_error)>(sym("rrx_rccl_last_error"));
+#ifdef RTE_USE_SP
+            allgather = reinterpret_cast<decltype(allgather)>(sym("rrx_allgather_fluxes_f32"));
+#else
+            allgather = reinterpret_cast<decltype(allgather)>(sym("rrx_allgather_fluxes_f64"));
+#endif
+            reinterpret_cast<decltype(&rrx_column_range)>(sym("rrx_column_range"))(rank, world, n_col_total, &col_s, &col_e);
+            int n_dev = 0;
+            rrx_host::check(rrx_device_count(&n_dev));
+            if (n_dev < 1) throw std::runtime_error("no GPU visible");
+            rrx_host::check(rrx_set_device(rank % n_dev));
+            const char* id_file = std::getenv("RRX_COMM_FILE");
+            if (!id_file) throw std::runtime_error("RRX_COMM_FILE is not set (ranks are started by --ngpus)");
+            char id[RRX_COMM_ID_BYTES];
+            if (rank == 0) { check(get_unique_id(id), "rrx_comm_get_unique_id"); check(id_to_file(id_file, id), "rrx_comm_id_to_file"); }
+            else check(id_from_file(id_file, id, 120), "rrx_comm_id_from_file");
+            check(create(world, rank, id, &comm), "rrx_comm_create");
+        }
+
+        // (n_local, rest...) with the column fastest -> (n_total, rest...) on every rank
+        template<int N>
+        Array_gpu<Float,N> gather(const Array_gpu<Float,N>& local, const int n_col_total) const
+        {
+            if (world == 1) return local;
+            std::array<int,N> d;
+            int nrows = 1;
+            for (int i=1; i<=N; ++i) { d[i-1] = local.dim(i); if (i > 1) nrows *= local.dim(i); }
+            d[0] = n_col_total;
+            Array_gpu<Float,N> full(d);
+            const int n_max = (n_col_total + world - 1) / world;
+            Array_gpu<Float,1> scratch({(world + 1) * nrows * n_max});
+            check(allgather(comm, nrows, n_col_total, local.ptr(), full.ptr(), scratch.ptr(), nullptr), "rrx_allgather_fluxes");
+            rrx_host::check(rrx_synchronize(nullptr));
+            return full;
+        }
+
+        ~Ranks() { if (comm && destroy) destroy(comm); }
+    };
+
+    // `--ngpus=N` / `--ngpus N` is taken out of the argument list (the other options are on/off switches)
+    int extract_ngpus(std::vector<std::string>& args)
+    {
+        int n = 1;
+        for (size_t i=0; i<args.size(); )
+        {
+            if (args[i].compare(0, 8, "--ngpus=") == 0) { n = std::atoi(args[i].c_str() + 8); args.erase(args.begin() + i); }
+            else if (args[i] == "--ngpus" && i + 1 < args.size()) { n = std::atoi(args[i+1].c_str()); args.erase(args.begin() + i, args.begin() + i + 2); }
+            else ++i;
+        }
+        if (n < 1) throw std::runtime_error("--ngpus needs a positive number");
+        return n;
+    }
+
+    // Launcher: N children of the stand-alone driver binary, nothing here touches the GPU. Returns the worst exit status.
+    int launch_ranks(const int n, const std::vector<std::string>& args)
+    {
+        char self[4096];
+        const ssize_t len = readlink("/proc/self/exe", self, sizeof(self) - 1);
+        std::string exe = len > 0 ? std::string(self, len) : std::string();
+        if (const char* e = std::getenv("RRX_DRIVER_EXE")) exe = e;
+        else if (exe.find("test_rte_rrtmgp_gpu") == std::string::npos) exe = Ranks::library_dir() + "/test_rte_rrtmgp_gpu";   // called through the library
+        if (access(exe.c_str(), X_OK) != 0) throw std::runtime_error("multi-GPU run needs the stand-alone driver binary, not found: " + exe);
+        const std::string id_file = "/tmp/rrx_comm_" + std::to_string(getpid()) + ".id";
+        std::remove(id_file.c_str());
+        std::vector<pid_t> pids;
+        for (int r=0; r<n; ++r)
+        {
+            std::vector<std::string> env_s;
+            for (char** e = environ; *e; ++e) env_s.emplace_back(*e);
+            env_s.push_back("RRX_RANK=" + std::to_string(r));
+            env_s.push_back("RRX_WORLD=" + std::to_string(n));
+            env_s.push_back("RRX_COMM_FILE=" + id_file);
+            if (!std::getenv("HSA_ENABLE_IPC_MODE_LEGACY")) env_s.push_back("HSA_ENABLE_IPC_MODE_LEGACY=0");
+            std::vector<char*> envp, argvp;
+            for (auto& e : env_s) envp.push_back(const_cast<char*>(e.c_str()));
+            envp.push_back(nullptr);
+            std::vector<std::string> a = args;
+            a.insert(a.begin(), exe);
+            for (auto& x : a) argvp.push_back(const_cast<char*>(x.c_str()));
+            argvp.push_back(nullptr);
+            pid_t pid;
+            if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argvp.data(), envp.data()) != 0)
+                throw std::runtime_error("cannot start rank " + std::to_string(r));
+            pids.push_back(pid);
+        }
+        int worst = 0;
+        for (const pid_t pid : pids)
+        {
+            int st = 0;
+            waitpid(pid, &st, 0);
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+            worst = std::max(worst, rc);
+        }
+        std::remove(id_file.c_str());
+        return worst;
+    }
+
     void read_and_set_vmr(const std::string& gas_name, const int n_col_x, const int n_col_y, const int n_lay,
                           const Netcdf_handle& input_nc, Gas_concs& gas_concs)
     {
@@ -128,43 +286,60 @@ void solve_radiation(int argc, char** argv)
     Netcdf_file input_nc("rte_rrtmgp_input.nc", Netcdf_mode::Read);
     const int n_col_x = input_nc.get_dimension_size("x");
     const int n_col_y = input_nc.get_dimension_size("y");
-    const int n_col = n_col_x * n_col_y;
+    const int n_col_glob = n_col_x * n_col_y;
+
+    // one rank per GPU (RRX_RANK / RRX_WORLD set by the --ngpus launcher): this rank's contiguous column range
+    Ranks ranks;
+    ranks.init(std::getenv("RRX_WORLD") ? std::atoi(std::getenv("RRX_WORLD")) : 1, std::getenv("RRX_RANK") ? std::atoi(std::getenv("RRX_RANK")) : 0, n_col_glob);
+    const int n_col = ranks.col_e - ranks.col_s;
+    const bool sharded = ranks.world > 1;
+    if (sharded)
+        Status::print_message("Rank " + std::to_string(ranks.rank) + " of " + std::to_string(ranks.world) + ": columns " +
+                              std::to_string(ranks.col_s + 1) + " - " + std::to_string(ranks.col_e));
+    auto shard2 = [&](const Array<Float,2>& a) { return (!sharded || a.size() == 0) ? a : a.subset({{ {ranks.col_s + 1, ranks.col_e}, {1, a.dim(2)} }}); };
+    auto shard_last = [&](const Array<Float,2>& a) { return !sharded ? a : a.subset({{ {1, a.dim(1)}, {ranks.col_s + 1, ranks.col_e} }}); };
+    auto shard1 = [&](const Array<Float,1>& a) { return !sharded ? a : a.subset({{ {ranks.col_s + 1, ranks.col_e} }}); };
     const int n_lay = input_nc.get_dimension_size("lay");
     const int n_lev = input_nc.get_dimension_size("lev");
 
-    Array<Float,2> p_lay(input_nc.get_variable<Float>("p_lay", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
-    Array<Float,2> t_lay(input_nc.get_variable<Float>("t_lay", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
-    Array<Float,2> p_lev(input_nc.get_variable<Float>("p_lev", {n_lev, n_col_y, n_col_x}), {n_col, n_lev});
-    Array<Float,2> t_lev(input_nc.get_variable<Float>("t_lev", {n_lev, n_col_y, n_col_x}), {n_col, n_lev});
+    const Array<Float,2> p_lay_all(input_nc.get_variable<Float>("p_lay", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay});
+    Array<Float,2> p_lay = shard2(p_lay_all);
+    Array<Float,2> t_lay = shard2(Array<Float,2>(input_nc.get_variable<Float>("t_lay", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
+    const Array<Float,2> p_lev_all(input_nc.get_variable<Float>("p_lev", {n_lev, n_col_y, n_col_x}), {n_col_glob, n_lev});
+    Array<Float,2> p_lev = shard2(p_lev_all);
+    Array<Float,2> t_lev = shard2(Array<Float,2>(input_nc.get_variable<Float>("t_lev", {n_lev, n_col_y, n_col_x}), {n_col_glob, n_lev}));
 
     Array<Float,2> col_dry;
     if (input_nc.variable_exists("col_dry"))
-        col_dry = Array<Float,2>(input_nc.get_variable<Float>("col_dry", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+        col_dry = shard2(Array<Float,2>(input_nc.get_variable<Float>("col_dry", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
 
-    Gas_concs gas_concs;
+    Gas_concs gas_concs_all;
     for (const char* gas : {"h2o", "co2", "o3", "n2o", "co", "ch4", "o2", "n2", "ccl4", "cfc11", "cfc12", "cfc22",
                             "hfc143a", "hfc125", "hfc23", "hfc32", "hfc134a", "cf4", "no2"})
-        read_and_set_vmr(gas, n_col_x, n_col_y, n_lay, input_nc, gas_concs);
+        read_and_set_vmr(gas, n_col_x, n_col_y, n_lay, input_nc, gas_concs_all);
+    const Gas_concs gas_concs = sharded ? Gas_concs(gas_concs_all, ranks.col_s + 1, n_col) : gas_concs_all;
 
     Array<Float,2> lwp, iwp, rel, dei;
     if (switch_cloud_optics)
     {
-        lwp = Array<Float,2>(input_nc.get_variable<Float>("lwp", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
-        iwp = Array<Float,2>(input_nc.get_variable<Float>("iwp", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
-        rel = Array<Float,2>(input_nc.get_variable<Float>("rel", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
-        dei = Array<Float,2>(input_nc.get_variable<Float>("dei", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+        lwp = shard2(Array<Float,2>(input_nc.get_variable<Float>("lwp", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
+        iwp = shard2(Array<Float,2>(input_nc.get_variable<Float>("iwp", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
+        rel = shard2(Array<Float,2>(input_nc.get_variable<Float>("rel", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
+        dei = shard2(Array<Float,2>(input_nc.get_variable<Float>("dei", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
     }
 
     ////// CREATE THE OUTPUT FILE //////
     Status::print_message("Preparing NetCDF output file.");
-    Netcdf_file output_nc("rte_rrtmgp_output.nc", Netcdf_mode::Create);
+    // every rank runs the same output code on the gathered arrays; only rank 0's file is kept
+    const std::string output_name = ranks.rank == 0 ? "rte_rrtmgp_output.nc" : "rte_rrtmgp_output.nc.rank" + std::to_string(ranks.rank);
+    Netcdf_file output_nc(output_name, Netcdf_mode::Create);
     output_nc.add_dimension("x", n_col_x);
     output_nc.add_dimension("y", n_col_y);
     output_nc.add_dimension("lay", n_lay);
     output_nc.add_dimension("lev", n_lev);
     output_nc.add_dimension("pair", 2);
-    output_nc.add_variable<Float>("p_lay", {"lay", "y", "x"}).insert(p_lay.v(), {0, 0, 0});
-    output_nc.add_variable<Float>("p_lev", {"lev", "y", "x"}).insert(p_lev.v(), {0, 0, 0});
+    output_nc.add_variable<Float>("p_lay", {"lay", "y", "x"}).insert(p_lay_all.v(), {0, 0, 0});
+    output_nc.add_variable<Float>("p_lev", {"lev", "y", "x"}).insert(p_lev_all.v(), {0, 0, 0});
 
     Gas_concs_gpu gas_concs_gpu(gas_concs);
     Array_gpu<Float,2> p_lay_gpu(p_lay), p_lev_gpu(p_lev), t_lay_gpu(t_lay), t_lev_gpu(t_lev), col_dry_gpu(col_dry);
@@ -195,8 +370,8 @@ void solve_radiation(int argc, char** argv)
 
         const int n_bnd_lw = rad_lw.get_n_bnd_gpu();
         const int n_gpt_lw = rad_lw.get_n_gpt_gpu();
-        Array<Float,2> emis_sfc(input_nc.get_variable<Float>("emis_sfc", {n_col_y, n_col_x, n_bnd_lw}), {n_bnd_lw, n_col});
-        Array<Float,1> t_sfc(input_nc.get_variable<Float>("t_sfc", {n_col_y, n_col_x}), {n_col});
+        Array<Float,2> emis_sfc = shard_last(Array<Float,2>(input_nc.get_variable<Float>("emis_sfc", {n_col_y, n_col_x, n_bnd_lw}), {n_bnd_lw, n_col_glob}));
+        Array<Float,1> t_sfc = shard1(Array<Float,1>(input_nc.get_variable<Float>("t_sfc", {n_col_y, n_col_x}), {n_col_glob}));
         Array_gpu<Float,2> emis_sfc_gpu(emis_sfc);
         Array_gpu<Float,1> t_sfc_gpu(t_sfc);
 
@@ -231,27 +406,27 @@ void solve_radiation(int argc, char** argv)
         if (switch_output_optical)
         {
             output_nc.add_variable<int>("lw_band_lims_gpt", {"band_lw", "pair"}).insert(rad_lw.get_band_lims_gpoint_gpu().v(), {0, 0});
-            output_nc.add_variable<Float>("lw_tau", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(lw_tau).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("lay_source", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(lay_source).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("lev_source", {"gpt_lw", "lev", "y", "x"}).insert(Array<Float,3>(lev_source).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("sfc_source", {"gpt_lw", "y", "x"}).insert(Array<Float,2>(sfc_source).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_tau", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(ranks.gather(lw_tau, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("lay_source", {"gpt_lw", "lay", "y", "x"}).insert(Array<Float,3>(ranks.gather(lay_source, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("lev_source", {"gpt_lw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(lev_source, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("sfc_source", {"gpt_lw", "y", "x"}).insert(Array<Float,2>(ranks.gather(sfc_source, n_col_glob)).v(), {0, 0, 0});
         }
         if (switch_fluxes)
         {
-            output_nc.add_variable<Float>("lw_flux_up" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_up ).v(), {0, 0, 0});
-            output_nc.add_variable<Float>("lw_flux_dn" , {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_dn ).v(), {0, 0, 0});
-            output_nc.add_variable<Float>("lw_flux_net", {"lev", "y", "x"}).insert(Array<Float,2>(lw_flux_net).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_flux_up" , {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(lw_flux_up, n_col_glob)).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_flux_dn" , {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(lw_flux_dn, n_col_glob)).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("lw_flux_net", {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(lw_flux_net, n_col_glob)).v(), {0, 0, 0});
             if (switch_heating_rates)
             {
                 Array_gpu<Float,2> hr;
                 compute_heating_rate(lw_flux_net, p_lev_gpu, hr);
-                output_nc.add_variable<Float>("lw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(hr).v(), {0, 0, 0});
+                output_nc.add_variable<Float>("lw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(ranks.gather(hr, n_col_glob)).v(), {0, 0, 0});
             }
             if (switch_output_bnd_fluxes)
             {
-                output_nc.add_variable<Float>("lw_bnd_flux_up" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_up ).v(), {0, 0, 0, 0});
-                output_nc.add_variable<Float>("lw_bnd_flux_dn" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_dn ).v(), {0, 0, 0, 0});
-                output_nc.add_variable<Float>("lw_bnd_flux_net", {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(lw_bnd_flux_net).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("lw_bnd_flux_up" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(lw_bnd_flux_up, n_col_glob)).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("lw_bnd_flux_dn" , {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(lw_bnd_flux_dn, n_col_glob)).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("lw_bnd_flux_net", {"band_lw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(lw_bnd_flux_net, n_col_glob)).v(), {0, 0, 0, 0});
             }
         }
     }
@@ -268,14 +443,14 @@ void solve_radiation(int argc, char** argv)
 
         const int n_bnd_sw = rad_sw.get_n_bnd_gpu();
         const int n_gpt_sw = rad_sw.get_n_gpt_gpu();
-        Array<Float,1> mu0(input_nc.get_variable<Float>("mu0", {n_col_y, n_col_x}), {n_col});
-        Array<Float,2> sfc_alb_dir(input_nc.get_variable<Float>("sfc_alb_dir", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col});
-        Array<Float,2> sfc_alb_dif(input_nc.get_variable<Float>("sfc_alb_dif", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col});
+        Array<Float,1> mu0 = shard1(Array<Float,1>(input_nc.get_variable<Float>("mu0", {n_col_y, n_col_x}), {n_col_glob}));
+        Array<Float,2> sfc_alb_dir = shard_last(Array<Float,2>(input_nc.get_variable<Float>("sfc_alb_dir", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col_glob}));
+        Array<Float,2> sfc_alb_dif = shard_last(Array<Float,2>(input_nc.get_variable<Float>("sfc_alb_dif", {n_col_y, n_col_x, n_bnd_sw}), {n_bnd_sw, n_col_glob}));
 
         Array<Float,1> tsi_scaling({n_col});
         if (input_nc.variable_exists("tsi"))
         {
-            Array<Float,1> tsi(input_nc.get_variable<Float>("tsi", {n_col_y, n_col_x}), {n_col});
+            Array<Float,1> tsi = shard1(Array<Float,1>(input_nc.get_variable<Float>("tsi", {n_col_y, n_col_x}), {n_col_glob}));
             const Float tsi_ref = rad_sw.get_tsi_gpu();
             for (int icol=1; icol<=n_col; ++icol) tsi_scaling({icol}) = tsi({icol}) / tsi_ref;
         }
@@ -294,7 +469,7 @@ void solve_radiation(int argc, char** argv)
         Aerosol_concs aerosol_concs;
         if (switch_aerosol_optics)
         {
-            rh_gpu = Array<Float,2>(input_nc.get_variable<Float>("rh", {n_lay, n_col_y, n_col_x}), {n_col, n_lay});
+            rh_gpu = shard2(Array<Float,2>(input_nc.get_variable<Float>("rh", {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
             for (int i=1; i<=11; ++i)
             {
                 const std::string name = std::string(i < 10 ? "aermr0" : "aermr") + std::to_string(i);
@@ -304,12 +479,12 @@ void solve_radiation(int argc, char** argv)
                 if (dims.size() == 1 && dims.count("lay"))
                     aerosol_concs.set_vmr(name, Array<Float,1>(input_nc.get_variable<Float>(name, {n_lay}), {n_lay}));
                 else if (dims.size() == 3 && dims.count("lay") && dims.count("y") && dims.count("x"))
-                    aerosol_concs.set_vmr(name, Array<Float,2>(input_nc.get_variable<Float>(name, {n_lay, n_col_y, n_col_x}), {n_col, n_lay}));
+                    aerosol_concs.set_vmr(name, Array<Float,2>(input_nc.get_variable<Float>(name, {n_lay, n_col_y, n_col_x}), {n_col_glob, n_lay}));
                 else
                     throw std::runtime_error("Illegal dimensions of \"" + name + "\" in input");
             }
         }
-        Aerosol_concs_gpu aerosol_concs_gpu(aerosol_concs);
+        Aerosol_concs_gpu aerosol_concs_gpu(sharded ? Aerosol_concs(aerosol_concs, ranks.col_s + 1, n_col) : aerosol_concs);
 
         Array_gpu<Float,3> sw_tau, ssa, g;
         Array_gpu<Float,2> toa_src;
@@ -347,33 +522,34 @@ void solve_radiation(int argc, char** argv)
         if (switch_output_optical)
         {
             output_nc.add_variable<int>("sw_band_lims_gpt", {"band_sw", "pair"}).insert(rad_sw.get_band_lims_gpoint_gpu().v(), {0, 0});
-            output_nc.add_variable<Float>("sw_tau", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(sw_tau).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("ssa", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(ssa).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("g", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(g).v(), {0, 0, 0, 0});
-            output_nc.add_variable<Float>("toa_source", {"gpt_sw", "y", "x"}).insert(Array<Float,2>(toa_src).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_tau", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(ranks.gather(sw_tau, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("ssa", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(ranks.gather(ssa, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("g", {"gpt_sw", "lay", "y", "x"}).insert(Array<Float,3>(ranks.gather(g, n_col_glob)).v(), {0, 0, 0, 0});
+            output_nc.add_variable<Float>("toa_source", {"gpt_sw", "y", "x"}).insert(Array<Float,2>(ranks.gather(toa_src, n_col_glob)).v(), {0, 0, 0});
         }
         if (switch_fluxes)
         {
-            output_nc.add_variable<Float>("sw_flux_up"    , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_up    ).v(), {0, 0, 0});
-            output_nc.add_variable<Float>("sw_flux_dn"    , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn    ).v(), {0, 0, 0});
-            output_nc.add_variable<Float>("sw_flux_dn_dir", {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_dn_dir).v(), {0, 0, 0});
-            output_nc.add_variable<Float>("sw_flux_net"   , {"lev", "y", "x"}).insert(Array<Float,2>(sw_flux_net   ).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_up"    , {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(sw_flux_up, n_col_glob)).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_dn"    , {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(sw_flux_dn, n_col_glob)).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_dn_dir", {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(sw_flux_dn_dir, n_col_glob)).v(), {0, 0, 0});
+            output_nc.add_variable<Float>("sw_flux_net"   , {"lev", "y", "x"}).insert(Array<Float,2>(ranks.gather(sw_flux_net, n_col_glob)).v(), {0, 0, 0});
             if (switch_heating_rates)
             {
                 Array_gpu<Float,2> hr;
                 compute_heating_rate(sw_flux_net, p_lev_gpu, hr);
-                output_nc.add_variable<Float>("sw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(hr).v(), {0, 0, 0});
+                output_nc.add_variable<Float>("sw_heating_rate", {"lay", "y", "x"}).insert(Array<Float,2>(ranks.gather(hr, n_col_glob)).v(), {0, 0, 0});
             }
             if (switch_output_bnd_fluxes)
             {
-                output_nc.add_variable<Float>("sw_bnd_flux_up"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_up    ).v(), {0, 0, 0, 0});
-                output_nc.add_variable<Float>("sw_bnd_flux_dn"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_dn    ).v(), {0, 0, 0, 0});
-                output_nc.add_variable<Float>("sw_bnd_flux_dn_dir", {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_dn_dir).v(), {0, 0, 0, 0});
-                output_nc.add_variable<Float>("sw_bnd_flux_net"   , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(sw_bnd_flux_net   ).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_up"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(sw_bnd_flux_up, n_col_glob)).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_dn"    , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(sw_bnd_flux_dn, n_col_glob)).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_dn_dir", {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(sw_bnd_flux_dn_dir, n_col_glob)).v(), {0, 0, 0, 0});
+                output_nc.add_variable<Float>("sw_bnd_flux_net"   , {"band_sw", "lev", "y", "x"}).insert(Array<Float,3>(ranks.gather(sw_bnd_flux_net, n_col_glob)).v(), {0, 0, 0, 0});
             }
         }
     }
     output_nc.sync();
+    if (ranks.rank != 0) std::remove(output_name.c_str());
     Status::print_message("###### Finished RTE+RRTMGP solver ######");
 }
 
@@ -383,7 +559,13 @@ extern "C" int rrx_host_main(int argc, char** argv)
 {
     try
     {
-        solve_radiation(argc, argv);
+        std::vector<std::string> args(argv + 1, argv + argc);
+        const int n_gpus = extract_ngpus(args);
+        if (n_gpus > 1 && !std::getenv("RRX_RANK"))
+            return launch_ranks(n_gpus, args);                       // this process only starts and awaits the ranks
+        std::vector<char*> av{argv[0]};
+        for (auto& a : args) av.push_back(const_cast<char*>(a.c_str()));
+        solve_radiation(int(av.size()), av.data());
     }
     catch (const std::exception& e)
     {

@@ -116,6 +116,21 @@ def test_driver_error_behaviour(case):
     assert run_driver(os.path.dirname(case["dir"])) == 1        # no input file there
 
 
+def test_driver_ngpus_option(case):
+    """--ngpus: one rank = the plain run (same bits); a malformed count is an error. More than one rank needs one GPU per rank
+    (RCCL refuses two ranks on one device), so the sharded path is covered piecewise: rrx_column_range against
+    sharding.column_range (tests/test_cabi.py), the pad / all-gather / place layout for world sizes 1..8 and a real one-rank
+    communicator (tests/test_gpu_parity.py::test_rccl_allgather_fluxes_c_abi)."""
+    assert run_driver(case["dir"], "--cloud-optics") == 0
+    _, ref = read_output(case["dir"])
+    assert run_driver(case["dir"], "--cloud-optics", "--ngpus=1") == 0
+    _, one = read_output(case["dir"])
+    assert run_driver(case["dir"], "--ngpus", "1", "--cloud-optics") == 0
+    for k in ref:
+        assert np.array_equal(ref[k], one[k]), k
+    assert run_driver(case["dir"], "--ngpus=0") == 1
+
+
 def test_delta_scale_on_lazy_zero_g_is_the_identity():
     """ADVICE r01: Optical_props_2str_gpu::delta_scale() on gas-only optical properties in the lazy g == 0 state must not
     hand the stale g array to the kernel (C++ self-check exported by the host library)."""
