@@ -54,6 +54,10 @@ int rrx_set_sw_variant(int v);
 /* column groups (8 or 16 columns x all levels) below which do_broadband falls back from the fused one-kernel form to
    per-g-point fluxes in a workspace + sum (default 512: measured break-even at C4 shapes is 256-512; 1 = always fused) */
 int rrx_set_broadband_min_groups(int n);
+/* g-point ranges per column group in the one-kernel broadband solvers: 0 (default) = as many (a power of two, at most 16) as it
+   takes to reach the workgroup count above when columns are few, 1 = never split, n = n ranges. Partial sums are added in
+   range order by a second kernel: deterministic, but not the association of the unsplit sum. */
+int rrx_set_broadband_gsplit(int n);
 /* 1 (default): the "direct" gas optics run the windowed kernel (LUT boxes staged in LDS) ahead of the gather kernel;
    0: gather kernel only (A/B runs, tests). Like the other switches it acts on the calling host thread. */
 int rrx_set_gas_window(int on);

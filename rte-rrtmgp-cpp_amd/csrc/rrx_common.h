@@ -20,6 +20,8 @@ namespace rrx
         int lw_variant = 0;        // rrx_set_lw_variant: kernel tiling for A/B runs (0 = default)
         int sw_variant = 0;        // rrx_set_sw_variant
         int bb_min_groups = 512;   // rrx_set_broadband_min_groups: column groups needed for the one-pass broadband form
+        int bb_gsplit = 0;         // rrx_set_broadband_gsplit: g-point ranges per column group in that form (0 = as many as it
+                                   // takes to reach bb_min_groups workgroups, 1 = never split)
         int sync_waves = 1;        // partner waves issue their load bursts together (env RRX_SYNC, default on)
         int go_share = 1;          // Planck shared-cell path (env RRX_GO_SHARE, default on)
         int go_window = 1;         // windowed gas optics ahead of the gather kernel (env RRX_GO_WINDOW, default on)
@@ -164,6 +166,22 @@ namespace rrx
             hipStream_t st_;
             std::vector<void*> ptrs_;
     };
+}
+
+namespace rrx
+{
+    // Number of g-point ranges the one-kernel broadband solvers split their loop into when `groups` column groups alone would
+    // leave most of the chip idle (few columns per GPU: BASELINE C4 on 8 GPUs is 2 048 columns each). Each range sums its
+    // g-points in order into its own (nlev, ncol) partial; a second kernel adds the partials in range order, so the result is
+    // deterministic (it differs from the unsplit sum only in the association of the additions).
+    inline int broadband_gsplit(const int groups, const int ngpt)
+    {
+        const Tuning& t = tuning();
+        if (t.bb_gsplit >= 1) return std::min(t.bb_gsplit, ngpt);
+        int n = 1;
+        while (groups*n < t.bb_min_groups && n < 16 && 2*n*4 <= ngpt) n *= 2;
+        return n;
+    }
 }
 
 #define RRX_TRY try {

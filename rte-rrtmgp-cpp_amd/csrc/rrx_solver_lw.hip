@@ -340,7 +340,7 @@ lw_noscat_scan_kernel(
 //          g-point instead of three, and the Planck kernel writes one instead of two (LW chain at C4: 9.9 -> 7.5 ms).
 //          The band's B values sit in per-thread LDS columns and are refreshed when the band changes.
 // One quadrature angle, no Jacobian (the general kernel above keeps those).
-template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, int EV = 2>
+template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = 2>
 __global__ void __launch_bounds__(256, 2)
 lw_noscat_bb_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
@@ -348,8 +348,11 @@ lw_noscat_bb_kernel(
         const F* __restrict__ tau, const F* __restrict__ lay_source /* or pfrac */, const F* __restrict__ lev_source,
         const F* __restrict__ blay, const F* __restrict__ blev, const int* __restrict__ gpoint_bands,
         const F* __restrict__ sfc_emis, const F* __restrict__ sfc_src, const F* __restrict__ inc_flux,
-        F* __restrict__ flux_up, F* __restrict__ flux_dn)
+        F* __restrict__ flux_up, F* __restrict__ flux_dn, const int gper, const size_t part_stride)
 {
+    // GS: blockIdx.y = g-point range [g_lo, g_hi) of this workgroup; its sums go to partial array blockIdx.y
+    const int g_lo = GS ? blockIdx.y*gper : 0, g_hi = GS ? min(ngpt, g_lo + gper) : ngpt;
+    if constexpr (GS) { flux_up += blockIdx.y*part_stride; flux_dn += blockIdx.y*part_stride; }
     constexpr int CL = CLT, LL = 64/CLT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & (CL-1), ll = lane / CL;
@@ -410,12 +413,12 @@ lw_noscat_bb_kernel(
     };
 
     Loads nxt;
-    if constexpr (PRE) issue(0, nxt);
+    if constexpr (PRE) issue(g_lo, nxt);
     int cur_bnd = -1;
     const F wgt = weights[0];
     const F scale = pi * wgt;
 
-    for (int igpt=0; igpt<ngpt; ++igpt)
+    for (int igpt=g_lo; igpt<g_hi; ++igpt)
     {
     if constexpr (!PRE) __syncthreads();        // partner waves issue their load bursts together
     Loads cur;
@@ -515,7 +518,7 @@ lw_noscat_bb_kernel(
             {
                 // every wave of the workgroup is here: the waves that share 128-B lines ask for them together
                 __builtin_amdgcn_sched_barrier(0);
-                issue(min(igpt + 1, ngpt - 1), nxt);            // (last iteration: a harmless re-read)
+                issue(min(igpt + 1, g_hi - 1), nxt);            // (last iteration: a harmless re-read)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -777,18 +780,39 @@ bool launch_bb2(
         const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
 {
     if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
-    const dim3 grid(ceil_div(ncol, (4/W)*CLT*V), 1);
+    const int groups = ceil_div(ncol, (4/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
+    if (need > ((CLT == 16) ? 9 : 5)) return false;
+    // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
+    const int nsplit = broadband_gsplit(groups, ngpt);
+    const int gper = ceil_div(ngpt, nsplit);
+    const size_t nlevcol = size_t(ncol)*(nlay+1);
+    StreamScratch scratch(st);
+    F* out_up = flux_up; F* out_dn = flux_dn;
+    if (nsplit > 1) { out_up = scratch.get<F>(2*nsplit*nlevcol); out_dn = out_up + nsplit*nlevcol; }
+    const dim3 grid(groups, nsplit);
 #define RRX_LW_B2(KK) if (need <= KK) { \
-        if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
-            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn); \
+        if (nsplit > 1 && pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
+        else if (nsplit > 1) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
+        else if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
         else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
-            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn); \
-        return true; }
+            lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
+        break; }
+    do {
     if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
     else                     { RRX_LW_B2(2) RRX_LW_B2(3) RRX_LW_B2(5) }
+    } while (false);
+    if (nsplit > 1)
+    {
+        const int nb = ceil_div(nlevcol, 256);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, out_up, flux_up);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, out_dn, flux_dn);
+    }
+    return true;
 #undef RRX_LW_B2
-    return false;
 }
 
 // broadband fluxes from tau + (lay_source, lev_source) [LITE = false] or tau + Planck fractions and band Planck functions
@@ -840,11 +864,13 @@ int lw_solver_noscat_impl(
     const int g_lw_variant = tuning().lw_variant;
     const int g_bb_min_groups = tuning().bb_min_groups;
 
-    // broadband mode, fused form: g-point sums kept in registers, no per-g-point fluxes in memory. Taken when there are
-    // enough column groups to fill the chip without splitting the g-point range (which keeps sum_broadband's order).
+    // broadband mode, fused form: g-point sums kept in registers, no per-g-point fluxes in memory. With enough column groups
+    // to fill the chip one workgroup sums all g-points in order (sum_broadband's order); with fewer the g-point range is split
+    // over grid.y and the partial sums are added in range order (rrx::broadband_gsplit).
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+    const bool second_gen = (g_lw_variant == 0 || g_lw_variant == 13);        // splits its g-point loop when columns are few
     if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && ncol % VBB == 0
-        && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
+        && (second_gen || ceil_div(ncol, CL*VBB) >= g_bb_min_groups))
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
         // default: the second-generation kernel (pipelined loads); variants 8 / 9 / 12 keep the first-generation tilings
@@ -853,6 +879,8 @@ int lw_solver_noscat_impl(
                                         (const F*)nullptr, (const F*)nullptr, (const int*)nullptr, sfc_emis, sfc_src, inc_flux,
                                         flux_up_loc, flux_dn_loc))
             return 0;
+        // the first-generation tilings do not split the g-point loop: only with enough column groups
+        if (ceil_div(ncol, CL*VBB) >= g_bb_min_groups) {
         // four waves per column group (K = 5 at 140 layers) leave room for the g-point sums AND 128-B row segments.
         // Measured at C4: fp32 2.15 ms against 2.28 ms with two waves / 64-B rows; fp64 3.94 against 3.15 ms (256 VGPRs,
         // 12 % idle level-lanes), so fp64 keeps two waves unless variant 9 asks for four.
@@ -870,6 +898,7 @@ int lw_solver_noscat_impl(
         if (launch_scan_bb<F,VBB,2>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                     sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return 0;
+        }
     }
 
     // broadband mode, general form: per-g-point fluxes go to a workspace, then are summed over g-points
@@ -974,7 +1003,7 @@ int lw_solver_noscat_fractions_impl(
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
         constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
         const int var = tuning().lw_variant;
-        if ((var == 0 || var == 13) && ceil_div(ncol, CL*VBB) >= tuning().bb_min_groups &&
+        if ((var == 0 || var == 13) &&
             lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return check_launch("rrx_lw_solver_noscat_fractions");

@@ -118,14 +118,14 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // requested right after the two-stream phase of g-point g, when the registers of its temporaries are free, and land
 // during the scans and replays; the next iteration finds them in registers. Measured at C4 (tools/sw_lab.hip): 5.3 -> 4.7 ms;
 // loads issued layer by layer inside the two-stream phase were still in flight when their layer came up.
-template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false>
+template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false>
 __global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
         const F* __restrict__ sfc_alb_dir, const F* __restrict__ sfc_alb_dif,
         const F* __restrict__ inc_flux_dir, const F* __restrict__ inc_flux_dif,
-        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir, const int sync_waves)
+        F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir, const int sync_waves, const int gper)
 {
     // per-thread private LDS columns (dynamic register indexing is not needed: j is a compile-time constant, but
     // two of the six per-layer arrays live here so that the kernel fits 2 waves per SIMD)
@@ -168,8 +168,9 @@ sw_2stream_scan_kernel(
             for (int v=0; v<V; ++v) { acc_dir[j][v] = F(0.); lds_acc_up[j*V+v][tid] = F(0.); lds_acc_dn[j*V+v][tid] = F(0.); }
     }
 
-    const int g_begin = BB ? 0 : blockIdx.y;
-    const int g_end = BB ? ngpt : blockIdx.y + 1;
+    // BB: blockIdx.y = g-point range of this workgroup, its sums go to partial array blockIdx.y (one range: the outputs)
+    const int g_begin = BB ? (GS ? blockIdx.y*gper : 0) : blockIdx.y;
+    const int g_end = BB ? (GS ? min(ngpt, g_begin + gper) : ngpt) : blockIdx.y + 1;
 
     // PRE: element offset of layer j inside one g-point slab, recomputed where needed (9 registers less than keeping them)
     auto off_of = [&](const int j) -> unsigned
@@ -181,9 +182,12 @@ sw_2stream_scan_kernel(
     if constexpr (PRE)
     {
         static_assert(BB && GZ && W == 2, "the pipelined form is the fused broadband kernel without g array");
+        const F* __restrict__ tau_0 = tau + size_t(g_begin)*ncl*nlay;
+        const F* __restrict__ ssa_0 = ssa + size_t(g_begin)*ncl*nlay;
         #pragma unroll
-        for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau + o); nw[j] = load_cols<F,V>(ssa + o); }
-        n_inc = load_cols<F,V>(inc_flux_dir + icol); n_adir = load_cols<F,V>(sfc_alb_dir + icol); n_adif = load_cols<F,V>(sfc_alb_dif + icol);
+        for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau_0 + o); nw[j] = load_cols<F,V>(ssa_0 + o); }
+        const size_t s0 = size_t(g_begin)*ncl + icol;
+        n_inc = load_cols<F,V>(inc_flux_dir + s0); n_adir = load_cols<F,V>(sfc_alb_dir + s0); n_adif = load_cols<F,V>(sfc_alb_dif + s0);
     }
 
     for (int igpt=g_begin; igpt<g_end; ++igpt)
@@ -321,7 +325,7 @@ sw_2stream_scan_kernel(
                 {
                     // every wave of the workgroup is here: the two waves that share each 128-B line ask for it together
                     __builtin_amdgcn_sched_barrier(0);
-                    const int gn = min(igpt + 1, ngpt - 1);           // (last iteration: a harmless re-read)
+                    const int gn = min(igpt + 1, g_end - 1);          // (last iteration: a harmless re-read)
                     const F* __restrict__ tau_n = tau + size_t(gn)*ncl*nlay;
                     const F* __restrict__ ssa_n = ssa + size_t(gn)*ncl*nlay;
                     #pragma unroll
@@ -523,7 +527,7 @@ sw_2stream_scan_kernel(
             if (t <= nlay)
             {
                 const int ml = top_at_1 ? t : nlay - t;
-                const size_t o = size_t(icol) + size_t(ml)*ncl;
+                const size_t o = size_t(icol) + size_t(ml)*ncl + (GS ? size_t(blockIdx.y)*ncl*nlev : size_t(0));
                 Vec<F,V> u, d, r;
                 #pragma unroll
                 for (int v=0; v<V; ++v) { u.v[v] = lds_acc_up[j*V+v][tid]; d.v[v] = lds_acc_dn[j*V+v][tid]; r.v[v] = acc_dir[j][v]; }
@@ -639,7 +643,7 @@ bool launch_scan(hipStream_t st,
     const int need = ceil_div(nlay+1, LL*W);
 #define RRX_SW_K(KK) if (need <= KK) { sw_2stream_scan_kernel<F,V,KK,W><<<grid, 256, 0, st>>>( \
         ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-        flux_up, flux_dn, flux_dir, tuning().sync_waves); return true; }
+        flux_up, flux_dn, flux_dir, tuning().sync_waves, 1); return true; }
     if constexpr (W == 1) { RRX_SW_K(4) RRX_SW_K(8) RRX_SW_K(12) RRX_SW_K(18) RRX_SW_K(24) RRX_SW_K(33) }
     else                  { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6)  RRX_SW_K(9)  RRX_SW_K(12) RRX_SW_K(17) }
 #undef RRX_SW_K
@@ -652,23 +656,48 @@ bool launch_scan_bb(hipStream_t st,
         const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
-    const dim3 grid(ceil_div(ncol, 2*CL*V), 1);
+    const int groups = ceil_div(ncol, 2*CL*V);
     const int need = ceil_div(nlay+1, LL*2);
+    if (need > 12) return false;
     const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
+    // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
+    const int nsplit = broadband_gsplit(groups, ngpt);
+    const int gper = ceil_div(ngpt, nsplit);
+    const size_t nlevcol = size_t(ncol)*(nlay+1);
+    StreamScratch scratch(st);
+    F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
+    if (nsplit > 1) { up = scratch.get<F>(3*nsplit*nlevcol); dn = up + nsplit*nlevcol; dr = dn + nsplit*nlevcol; }
+    const dim3 grid(groups, nsplit);
 #define RRX_SW_K(KK) if (need <= KK) { \
-        if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true><<<grid, 256, 0, st>>>( \
+        if (nsplit > 1 && g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true,true><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
+            up, dn, dr, tuning().sync_waves, gper); \
+        else if (nsplit > 1 && g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true,false,true><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            up, dn, dr, tuning().sync_waves, gper); \
+        else if (nsplit > 1) sw_2stream_scan_kernel<F,V,KK,2,true,false,false,true><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            up, dn, dr, tuning().sync_waves, gper); \
+        else if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true><<<grid, 256, 0, st>>>( \
+            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
+            up, dn, dr, tuning().sync_waves, gper); \
         else if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
+            up, dn, dr, tuning().sync_waves, gper); \
         else sw_2stream_scan_kernel<F,V,KK,2,true,false><<<grid, 256, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            flux_up, flux_dn, flux_dir, tuning().sync_waves); \
-        return true; }
-    RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12)
+            up, dn, dr, tuning().sync_waves, gper); \
+        break; }
+    do { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) } while (false);
 #undef RRX_SW_K
-    return false;
+    if (nsplit > 1)
+    {
+        const int nb = ceil_div(nlevcol, 256);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, up, flux_up);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, dn, flux_dn);
+        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, dr, flux_dir);
+    }
+    return true;
 }
 
 template<typename F>
@@ -687,10 +716,12 @@ int sw_solver_2stream_impl(
     const int g_sw_variant = tuning().sw_variant;
     const int g_bb_min_groups = tuning().bb_min_groups;
 
-    // broadband mode, fused form (see the kernel's BB note); taken when the column groups alone fill the chip
+    // broadband mode, fused form (see the kernel's BB note): one workgroup per column group sums all g-points in order when the
+    // column groups alone fill the chip, otherwise the g-point range is split over grid.y (rrx::broadband_gsplit)
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
+    (void)g_bb_min_groups;
     // (variant 8: fused broadband form without the pipelined loads, for A/B runs)
-    if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && ncol % VBB == 0 && ceil_div(ncol, CL*VBB) >= g_bb_min_groups)
+    if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && ncol % VBB == 0)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
             throw std::runtime_error("do_broadband needs flux_*_loc");
@@ -763,6 +794,7 @@ extern "C"
 {
 int rrx_set_sw_variant(int v) { rrx::tuning().sw_variant = v; return 0; }
 int rrx_set_broadband_min_groups(int n) { rrx::tuning().bb_min_groups = n; return 0; }
+int rrx_set_broadband_gsplit(int n) { rrx::tuning().bb_gsplit = n; return 0; }
 
 #define RRX_DEFINE_SW(F, SFX) \
 int rrx_sw_solver_2stream##SFX( \

@@ -461,6 +461,9 @@ class HipKernels:
         """column groups needed before do_broadband takes the fused one-kernel form (default 512; 1 = always)"""
         self.lib.call("rrx_set_broadband_min_groups", int(n))
 
+    def set_broadband_gsplit(self, n):
+        self.lib.call("rrx_set_broadband_gsplit", int(n))
+
     def set_variant(self, lw=None, sw=None):
         if lw is not None:
             self.lib.call("rrx_set_lw_variant", int(lw))

@@ -94,13 +94,15 @@ def test_broadband_mode_equals_sum_of_gpoints(kind, fused, ncol, nlay, top_at_1,
     """do_broadband through the whole chain, in both of its forms (per-g-point fluxes in a workspace + sum, and the
     fused kernels), on ragged column counts (partial wavefronts) and layer counts that pick different tilings."""
     h = []
-    hip_f64.set_broadband_min_groups(1 if fused else 1 << 30)
+    # workspace form: solver variant 7 (no one-kernel form); fused: one workgroup per column group, g-points summed in order
+    hip_f64.set_broadband_min_groups(1)
+    hip_f64.set_variant(lw=0 if fused else 7, sw=0 if fused else 7)
     try:
         for bb in (False, True):
             r, _ = _solve_both(hip_f64, hip_f64, kind, ncol, nlay, top_at_1, False, do_broadband=bb)
             h.append(r)
     finally:
-        hip_f64.set_broadband_min_groups(512)
+        hip_f64.set_broadband_min_groups(512); hip_f64.set_variant(lw=0, sw=0)
     for k in ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ()):
         assert cases.rel_err(h[1][k], h[0][k]) <= 1e-12, k
 
@@ -196,12 +198,13 @@ def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
     up = be.asarray
     zero = be.zeros(tau.shape)
     for bb, mg in ((False, 512), (True, 1 << 30), (True, 1)):
-        be.set_broadband_min_groups(mg)
+        be.set_broadband_min_groups(1)
+        be.set_variant(sw=7 if mg == 1 << 30 else 0)          # 7: workspace broadband form (no one-kernel form)
         try:
             a = be.sw_solver_2stream(False, up(tau), up(ssa), zero, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=bb)
             b = be.sw_solver_2stream(False, up(tau), up(ssa), None, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=bb)
         finally:
-            be.set_broadband_min_groups(512)
+            be.set_broadband_min_groups(512); be.set_variant(sw=0)
         for k in ("flux_up", "flux_dn", "flux_dir"):
             if bb and mg == 1:
                 e = cases.rel_err(be.to_numpy(b[k]), be.to_numpy(a[k]), floor=1e-6 if dt == "f64" else 1e-2)
@@ -519,12 +522,13 @@ def test_planck_lite_chain(dt, top_at_1, hip_f64, hip_f32):
     inc = be.asarray(rng.uniform(0, 3, (kd.ngpt, atm.ncol)))
     tol = 1e-12 if dt == "f64" else 2e-5
     for mg in (1, 1 << 30):                 # one-kernel form; fallback (sources rebuilt into scratch, general entry)
-        be.set_broadband_min_groups(mg)
+        be.set_broadband_min_groups(1)
+        be.set_variant(lw=7 if mg == 1 << 30 else 0)
         try:
             ref = be.lw_solver_noscat(top_at_1, sec, w, tau, lay, lev, emis, fr["sfc_src"], inc_flux=inc, do_broadband=True)
             got = be.lw_solver_noscat_fractions(top_at_1, kd, sec, w, tau, fr, emis, inc_flux=inc)
         finally:
-            be.set_broadband_min_groups(512)
+            be.set_broadband_min_groups(512); be.set_variant(lw=0)
         for k in ("flux_up", "flux_dn"):
             e = cases.rel_err(N(got[k]), N(ref[k]), floor=1e-6 if dt == "f64" else 1e-2)
             assert e <= tol, (k, mg, e)
@@ -629,3 +633,46 @@ def test_rccl_allgather_fluxes_c_abi(hip_f64):
     torch.cuda.synchronize()
     assert torch.equal(out, local)
     assert lib.rrx_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_broadband_solvers_with_split_gpoint_range(dt, top_at_1, hip_f64, hip_f32):
+    """Few columns per GPU (BASELINE C4 on 8 GPUs: 2 048 each): the one-kernel broadband solvers split their g-point loop over
+    grid.y and add the partial sums in range order (rrx_set_broadband_gsplit; default: automatic). Checked against the unsplit
+    one-kernel form for the automatic choice, an uneven split (5 ranges of 10 over 48 g-points) and the finest one, for the LW
+    solver on sources and on Planck fractions and the SW solver with and without an asymmetry array."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    tol = 2e-14 if dt == "f64" else 2e-6
+    kw = dict(ngpt=48, nbnd=3, npres=12, nflav=4, nminor_lower=7, nminor_upper=4)
+    atm0 = synthetic.make_atmosphere(90, 140, nbnd_lw=3, nbnd_sw=3, clouds=True, top_at_1=top_at_1, seed=17).astype(be.np_dtype)
+    atm = pipeline.upload_atmosphere(be, atm0)
+    kl, ks = be.upload_kdist(synthetic.make_kdist("lw", **kw).astype(be.np_dtype)), be.upload_kdist(synthetic.make_kdist("sw", **kw).astype(be.np_dtype))
+    cl = be.upload_lut({k: (v.astype(be.np_dtype) if isinstance(v, np.ndarray) else v) for k, v in synthetic.make_cloud_lut(3, "sw").items()})
+
+    def run():
+        out = {}
+        for name, r in (("lw_lite", pipeline.solve_lw(be, kl, atm, do_broadband=True)),
+                        ("lw_src", pipeline.solve_lw(be, kl, atm, do_broadband=True, lite=False)),
+                        ("sw_nog", pipeline.solve_sw(be, ks, atm, do_broadband=True)),
+                        ("sw_g", pipeline.solve_sw(be, ks, atm, cloud_lut=cl, delta_cloud=True, do_broadband=True))):
+            for k in ("flux_up", "flux_dn", "flux_dn_dir"):
+                if k in r:
+                    out[name + "." + k] = be.to_numpy(r[k])
+        return out
+
+    try:
+        be.set_broadband_min_groups(1); be.set_broadband_gsplit(1)
+        ref = run()                                   # one workgroup per column group sums all 48 g-points in order
+        be.set_broadband_min_groups(512)
+        worst = 0.0
+        for split in (0, 5, 16):
+            be.set_broadband_gsplit(split)
+            got = run()
+            assert set(got) == set(ref)
+            for k in ref:
+                err = cases.rel_err(got[k], ref[k]); worst = max(worst, err)
+                assert err <= tol, (split, k, err)
+        print(f"split g-point range vs unsplit, {dt}: worst relative difference {worst:.2e}")
+    finally:
+        be.set_broadband_min_groups(512); be.set_broadband_gsplit(0)
