@@ -11,6 +11,8 @@
 // The k-distribution tables are gathered through L1/L2 (neighbouring columns hit the same lines); the per-chunk
 // lists of minor contributors are built once per workgroup in LDS.
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 #include "rrx_common.h"
 #include "rrx_hip.h"
 
@@ -257,15 +259,21 @@ tau_absorption_kernel(
 {
     // todo != null: this launch finishes the workgroups the windowed kernel handed back (gas_window_kernel): a 1-D grid, block b
     // takes over workgroup todo[1+b] of the (todo_gx x .) grid; blocks beyond the count todo[0] have nothing to do
+    // (gridDim.y > 1 would spread each handed-back workgroup over several that take a share of the g-point chunks each;
+    //  measured at C4 with 4 shares: 0.44 -> 0.38 ms for SW, 0.27 -> 0.31 ms for LW -- the per-workgroup set-up dominates -- so
+    //  the launch keeps one workgroup per handed-back block)
     int blk_x = blockIdx.x, blk_y = blockIdx.y;
+    extern __shared__ int lds_int[];
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    int c_lo = 0, c_hi = nchunk;
     if (todo != nullptr)
     {
         if (int(blockIdx.x) >= todo[0]) return;
         const int blk = todo[1 + blockIdx.x];
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+        const int per = (nchunk + int(gridDim.y) - 1) / int(gridDim.y);
+        c_lo = int(blockIdx.y)*per; c_hi = min(nchunk, c_lo + per);
     }
-    extern __shared__ int lds_int[];
-    const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
     int* gflav = lds_int;                                   // [2][ngpt]
     int* gchg = lds_int + 2*ngpt;                           // [ngpt] 1 where the flavor of either regime changes
@@ -608,7 +616,7 @@ tau_absorption_kernel(
         }
     };
 
-    for (int c=0; c<nchunk; ++c)
+    for (int c=c_lo; c<c_hi; ++c)
     {
         const int c0 = c*GCH;
         const int n = rfl(mi.count(itr, c));
@@ -1127,6 +1135,17 @@ constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, 
 constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
 constexpr int NCW = 6;                       // minor contributors of a chunk with a staged window
 
+// RRX_GW_STATS=1: after a windowed launch, print how many workgroups were handed back to the gather kernel, and why
+inline void gas_window_stats(const char* what, const int* todo, const int nblk, hipStream_t st)
+{
+    static const bool on = std::getenv("RRX_GW_STATS") != nullptr;
+    if (!on) return;
+    int h[9];
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h, todo - 8, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::fprintf(stderr, "[gas window %s] %d of %d workgroups handed back: temperature %d, pressure %d, regimes %d, chunk form %d, eta %d\n",
+                 what, h[8], nblk, h[0], h[1], h[2], h[3], h[4]);
+}
+
 template<typename F> struct PlanckArgs
 {
     const F* pfracin; const F* tlev; const F* tsfc; int sfc_lay; int nPlanckTemp; const int* gpoint_bands;
@@ -1256,11 +1275,18 @@ gas_window_kernel(
         for (int c=0; c<nchunk; ++c) all_chunks = all_chunks && (cuni[itr*nchunk + c] != 0);
         fits = fits && all_chunks;
     }
-    auto hand_back = [&]()          // workgroup-uniform: the gather kernel redoes this workgroup from scratch
+    // workgroup-uniform: the gather kernel redoes this workgroup from scratch. The eight words in front of the list count the
+    // reasons (0 temperature spread, 1 pressure spread, 2 both regimes, 3 a chunk outside the staged form, 4 eta spread);
+    // RRX_GW_STATS=1 prints them
+    auto hand_back = [&](const int why)
     {
-        if (tid == 0) { const int k = atomicAdd(&todo[0], 1); todo[1 + k] = blockIdx.y*gridDim.x + blockIdx.x; }
+        if (tid == 0) { const int k = atomicAdd(&todo[0], 1); todo[1 + k] = blockIdx.y*gridDim.x + blockIdx.x; atomicAdd(&todo[why - 8], 1); }
     };
-    if (!fits) { hand_back(); return; }
+    if (!fits)
+    {
+        hand_back(!(red[1] - jt_lo < NTW) ? 0 : !(red[3] - jp_lo + 2 <= NPW) ? 1 : (red[4] != red[5]) ? 2 : 3);
+        return;
+    }
 
     const int tn = ntemp*neta;
     const size_t s_gpt = size_t(ntemp)*neta*(npres+1);
@@ -1341,7 +1367,7 @@ gas_window_kernel(
             const int je_hi = 31 - __clz(int(all_present));
             red_slot = (red_slot == 6) ? 8 : 6;
             if (tid == 0) red[red_slot] = 0;                            // visible after the next barrier
-            if (je_hi - je_lo + 2 > NEW) { hand_back(); return; }
+            if (je_hi - je_lo + 2 > NEW) { hand_back(4); return; }
         }
         // (the regime is the same in every lane here: readfirstlane moves the chunk's list into scalar registers, so that the
         //  contributor conditions of the g-point loop are scalar branches instead of exec-mask sequences)
@@ -1554,8 +1580,8 @@ int gas_optics_lw_fractions_impl(
     int* todo = nullptr;
     if (windowed)
     {
-        todo = scratch.get<int>(size_t(1) + nblk);
-        if (hipMemsetAsync(todo, 0, sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+        todo = scratch.get<int>(size_t(9) + nblk) + 8;
+        if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
         const PlanckArgs<F> pa{pfracin, tlev, tsfc, sfc_lay, nPlanckTemp, gpoint_bands, totplnk_delta, totplnk, pfrac, blay, blev, sfc_src, sfc_src_jac};
         gas_window_kernel<F,2,true><<<grid, block, wlds, st>>>(
                 ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
@@ -1565,6 +1591,7 @@ int gas_optics_lw_fractions_impl(
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                 kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia,
                 tau, (F*)nullptr, (F*)nullptr, pa, todo);
+        gas_window_stats("lw + fractions", todo, nblk, st);
     }
     const dim3 g2 = windowed ? dim3(nblk) : grid;
     tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(
@@ -1577,7 +1604,7 @@ int gas_optics_lw_fractions_impl(
             (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr,
             (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr,
             tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x));
-    planck_fraction_kernel<F><<<g2, block, size_t(2)*ngpt*sizeof(int), st>>>(
+    planck_fraction_kernel<F><<<windowed ? dim3(nblk) : grid, block, size_t(2)*ngpt*sizeof(int), st>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin,
             totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x));
     RRX_CATCH("rrx_gas_optics_lw_fractions")
@@ -1618,8 +1645,8 @@ int tau_absorption_impl(
             hipStream_t st = static_cast<hipStream_t>(stream);
             StreamScratch scratch(st);
             const int nblk = int(grid.x)*int(grid.y);
-            int* todo = scratch.get<int>(size_t(1) + nblk);
-            if (hipMemsetAsync(todo, 0, sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+            int* todo = scratch.get<int>(size_t(9) + nblk) + 8;
+            if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
             gas_window_kernel<F,MODE,false><<<grid, block, wlds, st>>>(
                     ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
@@ -1628,6 +1655,7 @@ int tau_absorption_impl(
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                     kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g,
                     PlanckArgs<F>(), todo);
+            gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk, st);
             tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk), block, lds, st>>>(
                     ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,

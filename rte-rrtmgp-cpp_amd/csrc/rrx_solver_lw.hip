@@ -340,6 +340,9 @@ lw_noscat_scan_kernel(
 //          g-point instead of three, and the Planck kernel writes one instead of two (LW chain at C4: 9.9 -> 7.5 ms).
 //          The band's B values sit in per-thread LDS columns and are refreshed when the band changes.
 // One quadrature angle, no Jacobian (the general kernel above keeps those).
+#ifndef RRX_LW_LACC
+#define RRX_LW_LACC 1
+#endif
 template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = 2>
 __global__ void __launch_bounds__(256, 2)
 lw_noscat_bb_kernel(
@@ -370,11 +373,19 @@ lw_noscat_bb_kernel(
     const F pi = F(3.14159265358979323846);
     const F tau_thres = sqrt(sqrt(Lim<F>::eps()));
 
-    F acc_up[K][V], acc_dn[K][V];
+    // g-point sums of the lane's K levels: in LDS columns for fp64 (the 4*K registers they would take push the kernel past 256
+    // VGPRs into scratch; LDS has room for them at the two workgroups per CU the registers allow), in registers for fp32
+    constexpr bool LACC = RRX_LW_LACC && sizeof(F) == 8 && V == 1;
+    __shared__ F lds_acc[LACC ? 2*K*V : 1][256];
+    F acc_up[LACC ? 1 : K][V], acc_dn[LACC ? 1 : K][V];
     #pragma unroll
     for (int j=0; j<K; ++j)
         #pragma unroll
-        for (int v=0; v<V; ++v) { acc_up[j][v] = F(0.); acc_dn[j][v] = F(0.); }
+        for (int v=0; v<V; ++v)
+        {
+            if constexpr (LACC) { lds_acc[j*V+v][tid] = F(0.); lds_acc[(K+j)*V+v][tid] = F(0.); }
+            else { acc_up[j][v] = F(0.); acc_dn[j][v] = F(0.); }
+        }
 
     // element offsets inside one g-point slab: sweep layer s = t0+j, sweep level t = t0+j (clamped into the domain)
     auto lay_off = [&](const int j) -> unsigned
@@ -563,10 +574,20 @@ lw_noscat_bb_kernel(
     {
         F dn = dn_in[v];
         #pragma unroll
-        for (int j=0; j<K; ++j) { add_rounded(acc_dn[j][v], scale*dn); dn = tr[j][v]*dn + sdn[j][v]; }
+        for (int j=0; j<K; ++j)
+        {
+            if constexpr (LACC) { F a = lds_acc[(K+j)*V+v][tid]; add_rounded(a, scale*dn); lds_acc[(K+j)*V+v][tid] = a; }
+            else add_rounded(acc_dn[j][v], scale*dn);
+            dn = tr[j][v]*dn + sdn[j][v];
+        }
         F up = up_in[v];
         #pragma unroll
-        for (int j=K-1; j>=0; --j) { up = tr[j][v]*up + sup[j][v]; add_rounded(acc_up[j][v], scale*up); }
+        for (int j=K-1; j>=0; --j)
+        {
+            up = tr[j][v]*up + sup[j][v];
+            if constexpr (LACC) { F a = lds_acc[j*V+v][tid]; add_rounded(a, scale*up); lds_acc[j*V+v][tid] = a; }
+            else add_rounded(acc_up[j][v], scale*up);
+        }
     }
     }   // g-point loop
 
@@ -580,7 +601,11 @@ lw_noscat_bb_kernel(
             const size_t o = size_t(icol) + size_t(top_at_1 ? t : nlay - t)*ncl;
             Vec<F,V> u, d;
             #pragma unroll
-            for (int v=0; v<V; ++v) { u.v[v] = acc_up[j][v]; d.v[v] = acc_dn[j][v]; }
+            for (int v=0; v<V; ++v)
+            {
+                if constexpr (LACC) { u.v[v] = lds_acc[j*V+v][tid]; d.v[v] = lds_acc[(K+j)*V+v][tid]; }
+                else { u.v[v] = acc_up[j][v]; d.v[v] = acc_dn[j][v]; }
+            }
             store_cols<F,V>(flux_up + o, u);
             store_cols<F,V>(flux_dn + o, d);
         }
