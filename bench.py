@@ -5,7 +5,8 @@ A step = gas optics (interpolation, major+minor absorption, Rayleigh) -> Planck 
 sw_solver_2stream -> broadband flux reduction, on a synthetic RCEMIP atmosphere + synthetic k-distribution with
 the real shapes; inputs and LUTs are resident in HBM before the timed region starts.
 Columns shard over ranks (one process per GPU, weak scaling: --ncol columns PER GPU); the only collective is the
-all-gather of the packed broadband fluxes (7 x nlev x ncol words per rank) at the end of each step.
+all-gather of the packed broadband fluxes (7 x nlev x ncol words per rank) of each step, which travels while the next step
+computes (sharding.FluxGatherer; the last one is awaited inside the timed region).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run as a child process)
@@ -202,6 +203,7 @@ def main():
     ap.add_argument("--sw-variant", type=int, default=0)
     ap.add_argument("--cpu-cols", type=int, default=6000, help="columns of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true", help="wait for each all-gather before the next solve starts (A/B of the pipelined exchange)")
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
     args = ap.parse_args()
     args.broadband = (args.flux_mode == "broadband" or args.broadband) and not args.per_gpoint
@@ -249,7 +251,7 @@ def main():
     atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
     solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap)
     do_gather = world > 1 and not args.no_gather
-    gatherer = sharding.FluxGatherer(ntot, solver.fluxes) if do_gather else None
+    gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
 
     def one_step():
         F = solver.step()
@@ -258,6 +260,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if gatherer is not None:
+        gatherer.finish()
     solver.enable_stage_events(args.steps)
 
     if world > 1:
@@ -266,6 +270,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    if gatherer is not None:
+        gatherer.finish()               # the last exchange is inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -57,36 +57,54 @@ def gather_fluxes(local, ncol_total, group=None):
 
 
 class FluxGatherer:
-    """The flux gather of a resident solver: buffers allocated once, ONE all_gather_into_tensor per solve, equal shards
-    gathered in place (no padding copy), ragged ones through a padded staging buffer. `result()` returns the
-    (nflux, nlev, ncol_total) view-or-copy of the last gather. Backend-agnostic: RCCL ("nccl") on GPUs, gloo in the CPU tests."""
+    """The flux gather of a resident solver: buffers allocated once, ONE all_gather_into_tensor per solve. `gather(local)` copies
+    the rank's packed fluxes (nflux, nlev, ncol_local) into a send buffer and starts the collective WITHOUT waiting for it, so
+    that the exchange of solve i travels over xGMI while solve i+1 computes (two send / receive buffer pairs alternate; the
+    previous collective is awaited before the next one starts). `result()` waits for the last gather and returns its
+    (nflux, nlev, ncol_total) array; `finish()` only waits. Ragged shards go through the same padded send buffer.
+    Backend-agnostic: RCCL ("nccl") on GPUs, gloo in the CPU tests."""
 
-    def __init__(self, ncol_total, local_like, group=None):
+    def __init__(self, ncol_total, local_like, group=None, pipelined=True):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.ncol_total = ncol_total
+        self.pipelined = pipelined
         nflux, nlev, nloc = local_like.shape
         self.shape = (nflux, nlev)
         self.nmax = -(-ncol_total // self.world)
         s, e = column_range(self.rank, self.world, ncol_total)
         assert e - s == nloc, f"rank {self.rank} owns {e - s} columns but its flux buffer holds {nloc}"
-        self.even = (ncol_total % self.world == 0)
-        self.out = torch.empty((self.world*nflux, nlev, self.nmax), dtype=local_like.dtype, device=local_like.device)
-        self.stage = None if self.even else torch.zeros((nflux, nlev, self.nmax), dtype=local_like.dtype, device=local_like.device)
+        self.nloc = nloc
+        kw = dict(dtype=local_like.dtype, device=local_like.device)
+        nbuf = 2 if pipelined else 1
+        self.send = [torch.zeros((nflux, nlev, self.nmax), **kw) for _ in range(nbuf)]
+        self.recv = [torch.empty((self.world*nflux, nlev, self.nmax), **kw) for _ in range(nbuf)]
+        self.work = None
+        self.last = None            # index of the buffer pair of the most recent gather
+        self.count = 0
 
     def gather(self, local):
-        if self.even:
-            src = local if local.is_contiguous() else local.contiguous()
+        i = self.count % len(self.send)
+        self.count += 1
+        self.finish()                                    # the previous exchange (it had a whole solve to complete)
+        self.send[i][..., :self.nloc].copy_(local)       # stream-ordered: the solver may overwrite `local` right away
+        if self.pipelined:
+            self.work = dist.all_gather_into_tensor(self.recv[i], self.send[i], group=self.group, async_op=True)
         else:
-            self.stage[..., :local.shape[-1]] = local
-            src = self.stage
-        dist.all_gather_into_tensor(self.out, src, group=self.group)
-        return self.out
+            dist.all_gather_into_tensor(self.recv[i], self.send[i], group=self.group)
+        self.last = i
+        return self.recv[i]
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
 
     def result(self):
+        self.finish()
         nflux, nlev = self.shape
-        out = self.out.view(self.world, nflux, nlev, self.nmax)
+        out = self.recv[self.last].view(self.world, nflux, nlev, self.nmax)
         parts = []
         for r in range(self.world):
             s, e = column_range(r, self.world, self.ncol_total)

@@ -62,10 +62,23 @@ def _bench_worker(rank, world, port, scaling, ncol, q):
         gat = sharding.FluxGatherer(ntot, local)
         gat.gather(local)
         got = gat.result().numpy()
+        # pipelined use, as in bench.py: the exchange is started and the "next solve" overwrites the source at once; three steps
+        # over the two buffer pairs, each result read only after a later gather was started
+        src = local.clone()
+        first = gat.gather(src); src.mul_(2.0)
+        second = gat.gather(src); src.mul_(2.0)
+        gat.gather(src); src.zero_()
+        got4 = gat.result().numpy()
+        nf, nl = local.shape[:2]
+        mine_of = lambda buf: buf.view(world, nf, nl, -1)[rank, :, :, :local.shape[-1]]
+        pipelined_ok = bool(np.array_equal(got4, 4.0*got) and torch.equal(mine_of(second), 2.0*local) and torch.equal(mine_of(first), 4.0*local))
+        sync = sharding.FluxGatherer(ntot, local, pipelined=False)
+        sync.gather(local)
+        pipelined_ok = pipelined_ok and bool(np.array_equal(sync.result().numpy(), got))
         if rank == 0:
             one = argparse.Namespace(ncol=ntot, nlay=20, scaling="strong")
             (s1, e1), full = bench.local_atmosphere(one, 2, 0, 1)
-            q.put(bool((s1, e1) == (0, ntot) and np.array_equal(got, solve(full))))
+            q.put(bool((s1, e1) == (0, ntot) and np.array_equal(got, solve(full)) and pipelined_ok))
     finally:
         dist.destroy_process_group()
 

@@ -676,3 +676,27 @@ def test_broadband_solvers_with_split_gpoint_range(dt, top_at_1, hip_f64, hip_f3
         print(f"split g-point range vs unsplit, {dt}: worst relative difference {worst:.2e}")
     finally:
         be.set_broadband_min_groups(512); be.set_broadband_gsplit(0)
+
+
+def test_pipelined_flux_gatherer_on_rccl_single_rank():
+    """sharding.FluxGatherer on the RCCL backend (one rank, so a copy): the collective is started without waiting, the source is
+    overwritten at once (as the next solve does), results are read after later gathers were started. The multi-rank layout is
+    covered on gloo (tests/test_dist_gloo.py); this pins the stream ordering on the device."""
+    import torch
+    import torch.distributed as dist
+    from rte_rrtmgp_cpp_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 2000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        local = torch.rand((7, 141, 4096), dtype=torch.float64, device="cuda:0")
+        ref = local.clone()
+        gat = sharding.FluxGatherer(4096, local)
+        src = local.clone()
+        first = gat.gather(src); src.mul_(2.0)
+        second = gat.gather(src); src.mul_(2.0)
+        gat.gather(src); src.zero_()
+        out = gat.result()
+        torch.cuda.synchronize()
+        assert torch.equal(out, 4.0*ref) and torch.equal(second.view(7, 141, 4096), 2.0*ref) and torch.equal(first.view(7, 141, 4096), 4.0*ref)
+    finally:
+        dist.destroy_process_group()
