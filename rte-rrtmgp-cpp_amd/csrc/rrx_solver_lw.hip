@@ -850,11 +850,18 @@ bool lw_fused_broadband(
         const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
 {
     const bool pre = tuning().lw_variant != 13;                 // 13: without the pipelined loads (A/B runs)
+    // fp32: 16 x 4 lanes with two columns per lane (128-B rows, K = 9) ahead of 8 x 8 lanes with four (variant 14 = the latter
+    // first, for A/B runs). Measured at C4 in the fractions form: 1.77 against 3.26 ms (the four-column lane state spills).
+    const bool v2_first = tuning().lw_variant != 14;
     if constexpr (sizeof(F) == 8)
         return launch_bb2<F,1,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                          blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
     else
     {
+        if (ncol % 2 == 0 && v2_first &&
+            launch_bb2<F,2,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
         if (ncol % 4 == 0 &&
             launch_bb2<F,4,4,8,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
@@ -893,13 +900,13 @@ int lw_solver_noscat_impl(
     // to fill the chip one workgroup sums all g-points in order (sum_broadband's order); with fewer the g-point range is split
     // over grid.y and the partial sums are added in range order (rrx::broadband_gsplit).
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
-    const bool second_gen = (g_lw_variant == 0 || g_lw_variant == 13);        // splits its g-point loop when columns are few
+    const bool second_gen = (g_lw_variant == 0 || g_lw_variant == 13 || g_lw_variant == 14);        // splits its g-point loop when columns are few
     if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && ncol % VBB == 0
         && (second_gen || ceil_div(ncol, CL*VBB) >= g_bb_min_groups))
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
         // default: the second-generation kernel (pipelined loads); variants 8 / 9 / 12 keep the first-generation tilings
-        if ((g_lw_variant == 0 || g_lw_variant == 13) &&
+        if (second_gen &&
             lw_fused_broadband<F,false>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                         (const F*)nullptr, (const F*)nullptr, (const int*)nullptr, sfc_emis, sfc_src, inc_flux,
                                         flux_up_loc, flux_dn_loc))
@@ -1028,7 +1035,7 @@ int lw_solver_noscat_fractions_impl(
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
         constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
         const int var = tuning().lw_variant;
-        if ((var == 0 || var == 13) &&
+        if ((var == 0 || var == 13 || var == 14) &&
             lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return check_launch("rrx_lw_solver_noscat_fractions");
