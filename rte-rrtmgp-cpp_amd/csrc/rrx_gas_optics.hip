@@ -1127,6 +1127,10 @@ planck_fraction_kernel(
 #ifndef RRX_GW_NPRE
 #define RRX_GW_NPRE 3      // minor contributors whose LDS reads go out together with the major term's
 #endif
+#ifndef RRX_GW_PAIR
+#define RRX_GW_PAIR 0     // 1: g-points of a chunk go in pairs where the chunk allows it (measured: SW stage 3.81 -> 3.69 ms alone,
+                          // but its registers collide with the batched staging, which brings more: 3.81 -> 3.37 ms)
+#endif
 #ifndef RRX_GW_ABL
 #define RRX_GW_ABL 0      // ablation builds (tools/ab_gw.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop
 #endif
@@ -1319,13 +1323,12 @@ gas_window_kernel(
     };
 
     // Planck-lite extras
-    [[maybe_unused]] F t_lev = F(0.), t_levp = F(0.), t_sfc = F(0.), b_sfc = F(0.), b_sfc2 = F(0.);
+    [[maybe_unused]] F b_sfc = F(0.), b_sfc2 = F(0.);     // (level / surface temperatures are re-read at each band change: once per 16 g-points)
     [[maybe_unused]] bool is_last = false, is_sfc = false;
     [[maybe_unused]] int cur_bnd = -1;
     [[maybe_unused]] const size_t ncv = size_t(ncol)*(nlay+1);
     if constexpr (PF)
     {
-        t_lev = pa.tlev[idx]; t_levp = pa.tlev[idx + ncol]; t_sfc = pa.tsfc[icol];
         is_last = ilay == nlay-1; is_sfc = ilay == pa.sfc_lay-1;
     }
 
@@ -1379,38 +1382,74 @@ gas_window_kernel(
         // ---- stage the boxes: pairs (T, T+1) are adjacent words of the tables (temperature is their fastest dimension)
         if (RRX_GW_ABL != 2)
         {
-            const int nmaj = ng*WBOX;
-            for (int q = tid; q < nmaj; q += 256)
+            // The loads of a box are issued together, before its LDS writes: one memory round trip per phase (major [+ Planck
+            // fractions]; Rayleigh + contributors 0-2; contributors 3-5 where there are any) instead of one per loop iteration
+            // and box. The loops have at most GCH*WBOX/256 = 3 and 1 iterations: unrolled, the pairs held in registers.
+            static_assert((GCH*WBOX) % 256 == 0 && GCH*MBOX <= 256 && NCW == 6, "staging phases are written for these box sizes");
+            constexpr int KMAJ = GCH*WBOX/256;
+            const int nmaj = ng*WBOX, nmin = ng*MBOX;
+            auto stage_major = [&](const F* __restrict__ table, Vec2* __restrict__ W)
             {
-                const int gi = q / WBOX, r = q % WBOX;
-                const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
-                const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
-                const size_t off = size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn;
-                Wmaj[gi*WBOX + r] = *reinterpret_cast<const Vec2u*>(kmajor + off);
-                if constexpr (PF) Wpf[gi*WBOX + r] = *reinterpret_cast<const Vec2u*>(pa.pfracin + off);
-            }
-            const int nmin = ng*MBOX;
-            for (int i=0; i<n; ++i)
-            {
-                const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
-                for (int q = tid; q < nmin; q += 256)
+                Vec2 v[KMAJ];
+                #pragma unroll
+                for (int k=0; k<KMAJ; ++k)
                 {
-                    const int gi = q / MBOX, r = q % MBOX;
-                    const int e = r / NTW, t = r % NTW;
-                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1);
-                    const int kg = min(max(c0 + gi, lo), hi-1);                  // clamped: always a valid table row
-                    Wmin[(i*GCH + gi)*MBOX + r] = *reinterpret_cast<const Vec2u*>(kmin + size_t(kg + koff)*tn + it_ + ie*ntemp);
+                    const int q = tid + 256*k;
+                    if (q < nmaj)
+                    {
+                        const int gi = q / WBOX, r = q % WBOX;
+                        const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
+                        const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
+                        v[k] = *reinterpret_cast<const Vec2u*>(table + size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn);
+                    }
+                }
+                #pragma unroll
+                for (int k=0; k<KMAJ; ++k)
+                {
+                    const int q = tid + 256*k;
+                    if (q < nmaj) W[q] = v[k];                                                  // gi*WBOX + r == q
+                }
+            };
+            if constexpr (!PF) stage_major(kmajor, Wmaj);
+            else
+            {
+                // (the fractions form runs at the register limit of three waves per SIMD -- batching its two major-type boxes
+                //  costs 84 B of scratch per lane and time -- so they keep the rolled loop, one pair of loads in flight per iteration)
+                for (int q = tid; q < nmaj; q += 256)
+                {
+                    const int gi = q / WBOX, r = q % WBOX;
+                    const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
+                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
+                    const size_t off = size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn;
+                    Wmaj[q] = *reinterpret_cast<const Vec2u*>(kmajor + off);
+                    Wpf[q] = *reinterpret_cast<const Vec2u*>(pa.pfracin + off);
                 }
             }
-            if constexpr (MODE == 1)
+            __builtin_amdgcn_sched_barrier(0);
+            const int gi_m = tid / MBOX, r_m = tid % MBOX;                  // this thread's node of a minor / Rayleigh box
+            const int it_m = min(jt_lo - 1 + r_m % NTW, ntemp-2), ie_m = min(max(je_lo - 1 + r_m / NTW, 0), neta-1);
+            auto minor_node = [&](const int i) -> Vec2
             {
-                const F* kr = krayl + size_t(itr)*tn*ngpt;
-                for (int q = tid; q < nmin; q += 256)
+                const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                const int kg = min(max(c0 + gi_m, lo), hi-1);                   // clamped: always a valid table row
+                return *reinterpret_cast<const Vec2u*>(kmin + size_t(kg + koff)*tn + it_m + ie_m*ntemp);
+            };
+            if (tid < nmin)
+            {
+                Vec2 v[3]; [[maybe_unused]] Vec2 vray;
+                if constexpr (MODE == 1)
+                    vray = *reinterpret_cast<const Vec2u*>(krayl + size_t(itr)*tn*ngpt + size_t(c0 + gi_m)*tn + it_m + ie_m*ntemp);
+                #pragma unroll
+                for (int i=0; i<3; ++i) if (i < n) v[i] = minor_node(i);
+                if constexpr (MODE == 1) Wray[tid] = vray;                                       // gi*MBOX + r == tid
+                #pragma unroll
+                for (int i=0; i<3; ++i) if (i < n) Wmin[(i*GCH + gi_m)*MBOX + r_m] = v[i];
+                if (n > 3)
                 {
-                    const int gi = q / MBOX, r = q % MBOX;
-                    const int e = r / NTW, t = r % NTW;
-                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1);
-                    Wray[gi*MBOX + r] = *reinterpret_cast<const Vec2u*>(kr + size_t(c0 + gi)*tn + it_ + ie*ntemp);
+                    #pragma unroll
+                    for (int i=3; i<NCW; ++i) if (i < n) v[i-3] = minor_node(i);
+                    #pragma unroll
+                    for (int i=3; i<NCW; ++i) if (i < n) Wmin[(i*GCH + gi_m)*MBOX + r_m] = v[i-3];
                 }
             }
         }
@@ -1433,82 +1472,141 @@ gas_window_kernel(
         // ---- the chunk's g-points, one per iteration (measured alternatives, all slower on MI355X: batches of 2-8 g-points
         // with their LDS reads issued together -- the registers cost the third wave per SIMD --, contributor reads preloaded
         // next to the major term's, per-contributor sweeps over the chunk, straight-line specialisations per contributor count)
-        if (RRX_GW_ABL != 3)
-        for (int gi=0; gi<ng; ++gi)
+        // One g-point: the reference's expression order. `U` g-points at once (RRX_GW_PAIR): the same expressions per g-point,
+        // written side by side so that the LDS reads of both go out together and the two dependent fp64 chains interleave
+        // (a single chain leaves the SIMD idle for most of each LDS round trip with three waves to cover it). The paired form
+        // is taken when every contributor of the chunk spans the whole chunk (the rule: intervals are band-aligned), so it
+        // needs no per-g-point range tests.
+        auto gstep = [&](auto U_, auto CHK_, const int gi0)
         {
-            const int ig = c0 + gi;
-            const Vec2* wm = Wmaj + gi*WBOX;
-            // corners: lower temperature node (jt-1) = .x of the pair, upper (jt) = .y; the upper node uses its own eta index
-            const Vec2 a0 = wm[m00], a1 = wm[m00 + NTW], a2 = wm[m00 + NEW*NTW], a3 = wm[m00 + NEW*NTW + NTW];
-            F k4 = a0.y, k5 = a1.y, k6 = a2.y, k7 = a3.y;
-            if (!wave_same_eta) { k4 = wm[m10].y; k5 = wm[m10 + NTW].y; k6 = wm[m10 + NEW*NTW].y; k7 = wm[m10 + NEW*NTW + NTW].y; }
-            F t = cm[0] * (fm[0]*a0.x + fm[1]*a1.x + fm[2]*a2.x + fm[3]*a3.x)
-                + cm[1] * (fm[4]*k4 + fm[5]*k5 + fm[6]*k6 + fm[7]*k7);
+            constexpr int U = decltype(U_)::value;
+            constexpr bool CHK = decltype(CHK_)::value;
+            Vec2 a0[U], a1[U], a2[U], a3[U]; F k4[U], k5[U], k6[U], k7[U], t[U];
+            #pragma unroll
+            for (int u=0; u<U; ++u)
+            {
+                const Vec2* wm = Wmaj + (gi0 + u)*WBOX;
+                // corners: lower temperature node (jt-1) = .x of the pair, upper (jt) = .y; the upper node uses its own eta index
+                a0[u] = wm[m00]; a1[u] = wm[m00 + NTW]; a2[u] = wm[m00 + NEW*NTW]; a3[u] = wm[m00 + NEW*NTW + NTW];
+                k4[u] = a0[u].y; k5[u] = a1[u].y; k6[u] = a2[u].y; k7[u] = a3[u].y;
+            }
+            if (!wave_same_eta)
+            {
+                #pragma unroll
+                for (int u=0; u<U; ++u)
+                {
+                    const Vec2* wm = Wmaj + (gi0 + u)*WBOX;
+                    k4[u] = wm[m10].y; k5[u] = wm[m10 + NTW].y; k6[u] = wm[m10 + NEW*NTW].y; k7[u] = wm[m10 + NEW*NTW + NTW].y;
+                }
+            }
+            #pragma unroll
+            for (int u=0; u<U; ++u)
+                t[u] = cm[0] * (fm[0]*a0[u].x + fm[1]*a1[u].x + fm[2]*a2[u].x + fm[3]*a3[u].x)
+                     + cm[1] * (fm[4]*k4[u] + fm[5]*k5[u] + fm[6]*k6[u] + fm[7]*k7[u]);
             #pragma unroll
             for (int i=0; i<NCW; ++i)                                   // ascending contributor index: the reference's order
             {
-                if (i < n && ig >= slo[i] && ig < shi[i])
+                if (i < n && (!CHK || (c0 + gi0 >= slo[i] && c0 + gi0 < shi[i])))
                 {
-                    const Vec2* wn = Wmin + (i*GCH + gi)*MBOX;
-                    const Vec2 c0v = wn[q0], c1v = wn[q0 + NTW];
-                    F m2 = c0v.y, m3 = c1v.y;
-                    if (!wave_same_eta) { m2 = wn[q1].y; m3 = wn[q1 + NTW].y; }
-                    const F kk = fn[0]*c0v.x + fn[1]*c1v.x + fn[2]*m2 + fn[3]*m3;
-                    t = t + kk * sc[i];
-                }
-            }
-            const size_t o = idx + size_t(ig)*ncl;
-            if constexpr (MODE == 2)
-            {
-                if (active) tau[o] = t;
-            }
-            else
-            {
-                const Vec2* wr = Wray + gi*MBOX;
-                const Vec2 r0 = wr[q0], r1 = wr[q0 + NTW];
-                F r2 = r0.y, r3 = r1.y;
-                if (!wave_same_eta) { r2 = wr[q1].y; r3 = wr[q1 + NTW].y; }
-                const F ray = ray_fac * (fn[0]*r0.x + fn[1]*r1.x + fn[2]*r2 + fn[3]*r3);
-                const F tt = t + ray;
-                if (active)
-                {
-                    tau[o] = tt;
-                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
-                    if (g != nullptr) g[o] = F(0.);
-                }
-            }
-            if constexpr (PF)
-            {
-                const Vec2* wp = Wpf + gi*WBOX;
-                const Vec2 p0 = wp[m00], p1 = wp[m00 + NTW], p2 = wp[m00 + NEW*NTW], p3 = wp[m00 + NEW*NTW + NTW];
-                F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
-                if (!wave_same_eta) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
-                const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
-                const int ibnd = pa.gpoint_bands[ig] - 1;
-                if (ibnd != cur_bnd)
-                {
-                    cur_bnd = ibnd;
-                    const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
-                    const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                    const F bv = interp1d(t_lev, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                    if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
-                    if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(t_levp, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                    if (is_sfc)
+                    Vec2 c0v[U], c1v[U]; F m2[U], m3[U];
+                    #pragma unroll
+                    for (int u=0; u<U; ++u)
                     {
-                        b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                        b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        const Vec2* wn = Wmin + (i*GCH + gi0 + u)*MBOX;
+                        c0v[u] = wn[q0]; c1v[u] = wn[q0 + NTW]; m2[u] = c0v[u].y; m3[u] = c1v[u].y;
                     }
-                }
-                if (active)
-                {
-                    pa.pfrac[o] = pfrac;
-                    if (is_sfc)
+                    if (!wave_same_eta)
                     {
-                        pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
-                        pa.sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
+                        #pragma unroll
+                        for (int u=0; u<U; ++u) { const Vec2* wn = Wmin + (i*GCH + gi0 + u)*MBOX; m2[u] = wn[q1].y; m3[u] = wn[q1 + NTW].y; }
+                    }
+                    #pragma unroll
+                    for (int u=0; u<U; ++u)
+                    {
+                        const F kk = fn[0]*c0v[u].x + fn[1]*c1v[u].x + fn[2]*m2[u] + fn[3]*m3[u];
+                        t[u] = t[u] + kk * sc[i];
                     }
                 }
             }
+            [[maybe_unused]] F ray[U];
+            if constexpr (MODE != 2)
+            {
+                Vec2 r0[U], r1[U]; F r2[U], r3[U];
+                #pragma unroll
+                for (int u=0; u<U; ++u) { const Vec2* wr = Wray + (gi0 + u)*MBOX; r0[u] = wr[q0]; r1[u] = wr[q0 + NTW]; r2[u] = r0[u].y; r3[u] = r1[u].y; }
+                if (!wave_same_eta)
+                {
+                    #pragma unroll
+                    for (int u=0; u<U; ++u) { const Vec2* wr = Wray + (gi0 + u)*MBOX; r2[u] = wr[q1].y; r3[u] = wr[q1 + NTW].y; }
+                }
+                #pragma unroll
+                for (int u=0; u<U; ++u) ray[u] = ray_fac * (fn[0]*r0[u].x + fn[1]*r1[u].x + fn[2]*r2[u] + fn[3]*r3[u]);
+            }
+            #pragma unroll
+            for (int u=0; u<U; ++u)
+            {
+                const int gi = gi0 + u, ig = c0 + gi;
+                const size_t o = idx + size_t(ig)*ncl;
+                if constexpr (MODE == 2)
+                {
+                    if (active) tau[o] = t[u];
+                }
+                else
+                {
+                    const F tt = t[u] + ray[u];
+                    if (active)
+                    {
+                        tau[o] = tt;
+                        ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
+                        if (g != nullptr) g[o] = F(0.);
+                    }
+                }
+                if constexpr (PF)
+                {
+                    const Vec2* wp = Wpf + gi*WBOX;
+                    const Vec2 p0 = wp[m00], p1 = wp[m00 + NTW], p2 = wp[m00 + NEW*NTW], p3 = wp[m00 + NEW*NTW + NTW];
+                    F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
+                    if (!wave_same_eta) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
+                    const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
+                    const int ibnd = pa.gpoint_bands[ig] - 1;
+                    if (ibnd != cur_bnd)
+                    {
+                        cur_bnd = ibnd;
+                        const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
+                        const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        const F bv = interp1d(pa.tlev[idx], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
+                        if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        if (is_sfc)
+                        {
+                            const F t_sfc = pa.tsfc[icol];
+                            b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                            b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                        }
+                    }
+                    if (active)
+                    {
+                        pa.pfrac[o] = pfrac;
+                        if (is_sfc)
+                        {
+                            pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
+                            pa.sfc_src_jac[icol + size_t(ig)*ncol] = pfrac * (b_sfc2 - b_sfc);
+                        }
+                    }
+                }
+            }
+        };
+
+        // every contributor of the chunk spans the chunk: no range tests, g-points can go in pairs
+        bool chunk_full = true;
+        #pragma unroll
+        for (int i=0; i<NCW; ++i) if (i < n && !(slo[i] <= c0 && shi[i] >= gend)) chunk_full = false;
+        constexpr int PAIR = (RRX_GW_PAIR && !(PF && sizeof(F) == 8)) ? 2 : 1;    // the fractions form has no registers to spare in fp64
+        if (RRX_GW_ABL != 3)
+        for (int gi=0; gi<ng; )
+        {
+            if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, std::false_type{}, gi); gi += 2; }
+            else { gstep(std::integral_constant<int,1>{}, std::true_type{}, gi); gi += 1; }
         }
     }
     (void)SZ;
