@@ -268,6 +268,9 @@ int rrx_get_from_subset##SFX(int ncol, int nlay, int nbnd, int ncol_in, int col_
 /* ---- small kernels the reference keeps inside its host classes ---- */ \
 /* src_cuda/Gas_optics_rrtmgp.cu:392-422 fill_gases_kernel (one gas per call, igas = 0 copies col_dry) */ \
 int rrx_fill_gases##SFX(int ncol, int nlay, int dim1, int dim2, int ngas, int igas, F* vmr_out, const F* vmr_in, F* col_gas, const F* col_dry, void* stream); \
+/* the same for all gases in one launch: vmr_in = HOST array of ngas device pointers, each (dim1[i], dim2[i]) = (1,1) scalar, \
+   (1,nlay) profile or (ncol,nlay) field; col_gas(ncol,nlay,0:ngas) with slot 0 = col_dry (the per-gas vmr copy is not produced) */ \
+int rrx_fill_gases_all##SFX(int ncol, int nlay, int ngas, const F* const* vmr_in, const int* dim1, const int* dim2, F* col_gas, const F* col_dry, void* stream); \
 /* src_cuda/Gas_optics_rrtmgp.cu:806-903 get_col_dry (three kernels fused) */ \
 int rrx_get_col_dry##SFX(int ncol, int nlay, const F* vmr_h2o, const F* plev, F* col_dry, void* stream); \
 /* src_cuda/Rte_lw.cu:37-56, Rte_sw.cu:34-54 expand_and_transpose: (nbnd,ncol) -> (ncol,ngpt) */ \

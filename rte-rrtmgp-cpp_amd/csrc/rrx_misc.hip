@@ -200,6 +200,28 @@ __global__ void fill_gases_kernel(const int ncol, const int nlay, const int dim1
     }
 }
 
+// all gases in one launch (the product chain: the per-gas vmr copy of fill_gases_kernel is not kept)
+constexpr int RRX_MAX_GASES = 32;
+template<typename F> struct GasTable { const F* vmr[RRX_MAX_GASES]; int dim1[RRX_MAX_GASES], dim2[RRX_MAX_GASES]; };
+
+template<typename F>
+__global__ void fill_gases_all_kernel(const int ncol, const int nlay, const int ngas, const GasTable<F> gt,
+                                      F* __restrict__ col_gas, const F* __restrict__ col_dry)
+{
+    const size_t ncl = size_t(ncol)*nlay;
+    RRX_GRID_STRIDE(i, ncl)
+    {
+        const F cd = col_dry[i];
+        col_gas[i] = cd;
+        for (int igas=0; igas<ngas; ++igas)
+        {
+            const F* __restrict__ src = gt.vmr[igas];
+            const F v = (gt.dim1[igas] == 1 && gt.dim2[igas] == 1) ? src[0] : (gt.dim1[igas] == 1 ? src[i / ncol] : src[i]);
+            col_gas[i + size_t(igas+1)*ncl] = v * cd;
+        }
+    }
+}
+
 template<typename F>
 __global__ void col_dry_kernel(const int ncol, const int nlay, const F* __restrict__ vmr_h2o, const F* __restrict__ plev, F* __restrict__ col_dry)
 {
@@ -473,6 +495,10 @@ int rrx_get_from_subset##SFX(int ncol, int nlay, int nbnd, int ncol_in, int col_
   get_from_subset_kernel<F><<<grid1d(size_t(ncol_in)*nrest), 256, 0, ST>>>(ncol, nrest, ncol_in, col_s_in, narr, p); RRX_CATCH("rrx_get_from_subset") } \
 int rrx_fill_gases##SFX(int ncol, int nlay, int dim1, int dim2, int ngas, int igas, F* vmr_out, const F* vmr_in, F* col_gas, const F* col_dry, void* stream) \
 { RRX_TRY (void)ngas; fill_gases_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, dim1, dim2, igas, vmr_out, vmr_in, col_gas, col_dry); RRX_CATCH("rrx_fill_gases") } \
+int rrx_fill_gases_all##SFX(int ncol, int nlay, int ngas, const F* const* vmr_in, const int* dim1, const int* dim2, F* col_gas, const F* col_dry, void* stream) \
+{ RRX_TRY if (ngas < 0 || ngas > RRX_MAX_GASES) throw std::runtime_error("more gases than rrx_fill_gases_all takes"); \
+  GasTable<F> gt; for (int i=0; i<ngas; ++i) { gt.vmr[i] = vmr_in[i]; gt.dim1[i] = dim1[i]; gt.dim2[i] = dim2[i]; } \
+  fill_gases_all_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, ngas, gt, col_gas, col_dry); RRX_CATCH("rrx_fill_gases_all") } \
 int rrx_get_col_dry##SFX(int ncol, int nlay, const F* vmr_h2o, const F* plev, F* col_dry, void* stream) \
 { RRX_TRY col_dry_kernel<F><<<grid1d(size_t(ncol)*nlay), 256, 0, ST>>>(ncol, nlay, vmr_h2o, plev, col_dry); RRX_CATCH("rrx_get_col_dry") } \
 int rrx_expand_and_transpose##SFX(int ncol, int nbnd, const int* band_lims_gpt, const F* arr_in, F* arr_out, void* stream) \

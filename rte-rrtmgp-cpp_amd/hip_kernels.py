@@ -376,6 +376,12 @@ class HipKernels:
         (/root/reference/src_cuda/Gas_optics_rrtmgp.cu:392-422,1023-1028)."""
         nlay, ncol = col_dry.shape
         col_gas = self.empty((kd.ngas+1, nlay, ncol))
+        vs = [vmr_by_name[name] for name in kd.gas_names]
+        if len(vs) <= 32:                      # one launch for all gases
+            dims = [((v.shape[1], v.shape[0]) if v.dim() == 2 else (1, 1)) for v in vs]
+            self._c("fill_gases_all", ncol, nlay, len(vs), (ctypes.c_void_p * len(vs))(*[v.data_ptr() for v in vs]),
+                    (ctypes.c_int * len(vs))(*[d[0] for d in dims]), (ctypes.c_int * len(vs))(*[d[1] for d in dims]), col_gas, col_dry)
+            return col_gas
         vmr = self.empty((kd.ngas, nlay, ncol))
         self._c("fill_gases", ncol, nlay, ncol, nlay, kd.ngas, 0, vmr, col_dry, col_gas, col_dry)
         for i, name in enumerate(kd.gas_names, start=1):

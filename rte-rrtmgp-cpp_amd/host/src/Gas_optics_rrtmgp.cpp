@@ -397,6 +397,17 @@ void Gas_optics_rrtmgp_gpu::fill_col_gas(
 {
     const int ngas = this->gas_names.dim(1);
     col_gas.set_dims({ncol, nlay, ngas+1});
+    if (ngas <= 32)                             // one launch for all gases
+    {
+        const Float* src[32]; int d1[32], d2[32];
+        for (int igas=1; igas<=ngas; ++igas)
+        {
+            const Array_gpu<Float,2>& v = gas_desc.get_vmr(this->gas_names({igas}));
+            src[igas-1] = v.ptr(); d1[igas-1] = v.dim(1); d2[igas-1] = v.dim(2);
+        }
+        RRX_CALL(rrx_fill_gases_all, ncol, nlay, ngas, src, d1, d2, col_gas.ptr(), col_dry.ptr());
+        return;
+    }
     Array_gpu<Float,3> vmr({ncol, nlay, ngas});
     for (int igas=0; igas<=ngas; ++igas)
     {
