@@ -255,13 +255,13 @@ tau_absorption_kernel(
         const int* __restrict__ jeta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
         const F* __restrict__ krayl,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const InterpArgs<F> ia,
-        const int* __restrict__ todo = nullptr, const int todo_gx = 1)
+        const int* __restrict__ todo = nullptr, const int todo_gx = 1, const int todo_nblk = 1, const int todo_nz = 1)
 {
     // todo != null: this launch finishes the workgroups the windowed kernel handed back (gas_window_kernel): a 1-D grid, block b
-    // takes over workgroup todo[1+b] of the (todo_gx x .) grid; blocks beyond the count todo[0] have nothing to do
-    // (gridDim.y > 1 would spread each handed-back workgroup over several that take a share of the g-point chunks each;
-    //  measured at C4 with 4 shares: 0.44 -> 0.38 ms for SW, 0.27 -> 0.31 ms for LW -- the per-workgroup set-up dominates -- so
-    //  the launch keeps one workgroup per handed-back block)
+    // takes over entry todo[1+b] = workgroup + part * todo_nblk of the (todo_gx x . x todo_nz) grid -- a part is a share of the
+    // g-point chunks (gas_window_kernel's grid.z); blocks beyond the count todo[0] have nothing to do.
+    // (Spreading each handed-back workgroup over several gather workgroups was measured at C4 with 4 shares: 0.44 -> 0.38 ms for
+    //  SW, 0.27 -> 0.31 ms for LW -- the per-workgroup set-up dominates -- so there is one gather workgroup per entry.)
     int blk_x = blockIdx.x, blk_y = blockIdx.y;
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
@@ -269,10 +269,11 @@ tau_absorption_kernel(
     if (todo != nullptr)
     {
         if (int(blockIdx.x) >= todo[0]) return;
-        const int blk = todo[1 + blockIdx.x];
+        const int entry = todo[1 + blockIdx.x];
+        const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
-        const int per = (nchunk + int(gridDim.y) - 1) / int(gridDim.y);
-        c_lo = int(blockIdx.y)*per; c_hi = min(nchunk, c_lo + per);
+        const int per = (nchunk + todo_nz - 1) / todo_nz;
+        c_lo = part*per; c_hi = min(nchunk, c_lo + per);
     }
     const int nmax = max(nminorlower, nminorupper);
     int* gflav = lds_int;                                   // [2][ngpt]
@@ -1004,14 +1005,19 @@ planck_fraction_kernel(
         const int* __restrict__ gpoint_bands, const F* __restrict__ pfracin,
         const F totplnk_delta, const F* __restrict__ totplnk, const int* __restrict__ gpoint_flavor,
         F* __restrict__ pfrac_out, F* __restrict__ blay_out, F* __restrict__ blev_out,
-        F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1)
+        F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1,
+        const int todo_nblk = 1, const int todo_nz = 1)
 {
     int blk_x = blockIdx.x, blk_y = blockIdx.y;             // todo: see tau_absorption_kernel
+    int g_lo = 0, g_hi = ngpt;
     if (todo != nullptr)
     {
         if (int(blockIdx.x) >= todo[0]) return;
-        const int blk = todo[1 + blockIdx.x];
+        const int entry = todo[1 + blockIdx.x];
+        const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+        const int nchunk = (ngpt + GCH - 1) / GCH, per = (nchunk + todo_nz - 1) / todo_nz;
+        g_lo = min(part*per*GCH, ngpt); g_hi = min((part + 1)*per*GCH, ngpt);
     }
     extern __shared__ int lds_gflav[];                       // [2][ngpt] flavor (0-based) per regime and g-point
     for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*blockDim.y)
@@ -1044,7 +1050,7 @@ planck_fraction_kernel(
     bool same_eta = false;
     constexpr int PG = 4;              // g-points whose gathers are in flight together
 
-    for (int ig=0; ig<ngpt; )
+    for (int ig=g_lo; ig<g_hi; )
     {
         const int fl = lds_gflav[itropo*ngpt + ig];
         if (fl != cur_flav)
@@ -1055,10 +1061,10 @@ planck_fraction_kernel(
             b1 = unsigned( ci.jt    + (ci.je[1]-1)*s_eta + (ci.jp-1)*s_prs)*SZ;
             same_eta = (ci.je[0] == ci.je[1]);
         }
-        int ge = min(ig + PG, ngpt);
+        int ge = min(ig + PG, g_hi);
         #pragma unroll
         for (int u=PG-1; u>=1; --u)
-            if (ig + u < ngpt && lds_gflav[itropo*ngpt + ig + u] != fl) ge = ig + u;
+            if (ig + u < g_hi && lds_gflav[itropo*ngpt + ig + u] != fl) ge = ig + u;
 
         F v[PG][8];
         #pragma unroll
@@ -1138,6 +1144,15 @@ constexpr int NPW = 4, NEW = 4, NTW = 3;
 constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, planck_frac
 constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
 constexpr int NCW = 6;                       // minor contributors of a chunk with a staged window
+
+// Parts (grid.z) the chunk loop of the windowed kernel is shared out over: 1 when the (column, layer) workgroups alone fill the
+// chip a few times over (three resident per CU), else 2 or 4
+inline int gas_window_parts(const int nblk, const int nchunk)
+{
+    int nz = 1;
+    while (nblk*nz < 2048 && nz < 4 && 2*nz <= nchunk) nz *= 2;
+    return nz;
+}
 
 // RRX_GW_STATS=1: after a windowed launch, print how many workgroups were handed back to the gather kernel, and why
 inline void gas_window_stats(const char* what, const int* todo, const int nblk, hipStream_t st)
@@ -1273,10 +1288,13 @@ gas_window_kernel(
     atomicMin(&red[4], itr); atomicMax(&red[5], itr);
     __syncthreads();
     const int jt_lo = red[0], jp_lo = red[2];
+    // grid.z parts share out the chunks of a workgroup when the (column, layer) grid alone leaves CUs idle (few columns per GPU)
+    const int c_per = (nchunk + int(gridDim.z) - 1) / int(gridDim.z);
+    const int c_lo = int(blockIdx.z)*c_per, c_hi = min(nchunk, c_lo + c_per);
     bool fits = (red[1] - jt_lo < NTW) && (red[3] - jp_lo + 2 <= NPW) && (red[4] == red[5]);
     {
         bool all_chunks = true;
-        for (int c=0; c<nchunk; ++c) all_chunks = all_chunks && (cuni[itr*nchunk + c] != 0);
+        for (int c=c_lo; c<c_hi; ++c) all_chunks = all_chunks && (cuni[itr*nchunk + c] != 0);
         fits = fits && all_chunks;
     }
     // workgroup-uniform: the gather kernel redoes this workgroup from scratch. The eight words in front of the list count the
@@ -1284,7 +1302,12 @@ gas_window_kernel(
     // RRX_GW_STATS=1 prints them
     auto hand_back = [&](const int why)
     {
-        if (tid == 0) { const int k = atomicAdd(&todo[0], 1); todo[1 + k] = blockIdx.y*gridDim.x + blockIdx.x; atomicAdd(&todo[why - 8], 1); }
+        if (tid == 0)
+        {
+            const int k = atomicAdd(&todo[0], 1);
+            todo[1 + k] = int(blockIdx.y*gridDim.x + blockIdx.x) + int(blockIdx.z)*int(gridDim.x*gridDim.y);
+            atomicAdd(&todo[why - 8], 1);
+        }
     };
     if (!fits)
     {
@@ -1341,7 +1364,7 @@ gas_window_kernel(
     int red_slot = 6;                                                  // alternating pairs of reduction slots: 6/7, 8/9
 
     if (RRX_GW_ABL == 1) return;
-    for (int c=0; c<nchunk; ++c)
+    for (int c=c_lo; c<c_hi; ++c)
     {
         const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
         const int fl = gflav[itr*ngpt + c0];
@@ -1675,13 +1698,14 @@ int gas_optics_lw_fractions_impl(
     const bool windowed = tuning().go_window && wlds <= 64*1024;
     StreamScratch scratch(st);
     const int nblk = int(grid.x)*int(grid.y);
+    const int nz = gas_window_parts(nblk, nchunk);
     int* todo = nullptr;
     if (windowed)
     {
-        todo = scratch.get<int>(size_t(9) + nblk) + 8;
+        todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
         const PlanckArgs<F> pa{pfracin, tlev, tsfc, sfc_lay, nPlanckTemp, gpoint_bands, totplnk_delta, totplnk, pfrac, blay, blev, sfc_src, sfc_src_jac};
-        gas_window_kernel<F,2,true><<<grid, block, wlds, st>>>(
+        gas_window_kernel<F,2,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(
                 ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
                 kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
                 minor_scales_with_density_lower, minor_scales_with_density_upper,
@@ -1689,9 +1713,9 @@ int gas_optics_lw_fractions_impl(
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                 kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia,
                 tau, (F*)nullptr, (F*)nullptr, pa, todo);
-        gas_window_stats("lw + fractions", todo, nblk, st);
+        gas_window_stats("lw + fractions", todo, nblk*nz, st);
     }
-    const dim3 g2 = windowed ? dim3(nblk) : grid;
+    const dim3 g2 = windowed ? dim3(nblk*nz) : grid;
     tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
             kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
@@ -1701,10 +1725,10 @@ int gas_optics_lw_fractions_impl(
             kminor_start_lower, kminor_start_upper,
             (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr,
             (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr,
-            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x));
-    planck_fraction_kernel<F><<<windowed ? dim3(nblk) : grid, block, size_t(2)*ngpt*sizeof(int), st>>>(
+            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x), nblk, nz);
+    planck_fraction_kernel<F><<<g2, block, size_t(2)*ngpt*sizeof(int), st>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin,
-            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x));
+            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x), nblk, nz);
     RRX_CATCH("rrx_gas_optics_lw_fractions")
 }
 
@@ -1743,9 +1767,10 @@ int tau_absorption_impl(
             hipStream_t st = static_cast<hipStream_t>(stream);
             StreamScratch scratch(st);
             const int nblk = int(grid.x)*int(grid.y);
-            int* todo = scratch.get<int>(size_t(9) + nblk) + 8;
+            const int nz = gas_window_parts(nblk, nchunk);
+            int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
-            gas_window_kernel<F,MODE,false><<<grid, block, wlds, st>>>(
+            gas_window_kernel<F,MODE,false><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(
                     ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper,
@@ -1753,8 +1778,8 @@ int tau_absorption_impl(
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                     kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g,
                     PlanckArgs<F>(), todo);
-            gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk, st);
-            tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk), block, lds, st>>>(
+            gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk*nz, st);
+            tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk*nz), block, lds, st>>>(
                     ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper,
@@ -1762,7 +1787,7 @@ int tau_absorption_impl(
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                     kminor_start_lower, kminor_start_upper,
                     tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
-                    tau, ssa, g, ia, todo, int(grid.x));
+                    tau, ssa, g, ia, todo, int(grid.x), nblk, nz);
             return check_launch(name);
         }
     }
