@@ -1130,9 +1130,6 @@ planck_fraction_kernel(
 // its id to a todo list and leaves; the gather kernel is launched behind on exactly those workgroups.
 // PF: the Planck fractions ride along (planck_frac has kmajor's layout: same box, same corner weights) together with the band
 // Planck functions and the surface terms -- the whole "Planck-lite" output of planck_fraction_kernel.
-#ifndef RRX_GW_NPRE
-#define RRX_GW_NPRE 3      // minor contributors whose LDS reads go out together with the major term's
-#endif
 #ifndef RRX_GW_PAIR
 #define RRX_GW_PAIR 0     // 1: g-points of a chunk go in pairs where the chunk allows it (measured: SW stage 3.81 -> 3.69 ms alone,
                           // but its registers collide with the batched staging, which brings more: 3.81 -> 3.37 ms)
