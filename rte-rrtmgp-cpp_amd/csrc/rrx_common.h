@@ -106,8 +106,16 @@ namespace rrx
         e = fma(-x, r, 1.0); r = fma(r, e, r);
         return r;
     }
-    // fp32 kernels are HBM-bound with VALU to spare: keep the correctly rounded division there
+#ifndef RRX_F32_IEEE_RCP
+    __device__ __forceinline__ float fast_rcp(const float x)
+    {
+        float r = __builtin_amdgcn_rcpf(x);
+        const float e = fmaf(-x, r, 1.0f); r = fmaf(r, e, r);
+        return r;
+    }
+#else
     __device__ __forceinline__ float fast_rcp(const float x) { return 1.0f / x; }
+#endif
 
     // exp(x) for finite x <= 0 (layer transmissivities exp(-tau*k), exp(-tau/mu0)): libm's exp without its overflow /
     // special-value handling. Range reduction x = n ln2 + r, |r| <= ln2/2 (ln2 split so that n*ln2_hi is exact), minimax

@@ -81,18 +81,8 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
     const F omk2 = F(1.) - k_mu*k_mu;
     const F fact = (abs(omk2) > tmin) ? omk2 : tmin;
     const F D = k * (F(1.) + exp_minus2ktau) + gamma1 * (F(1.) - exp_minus2ktau);
-    F rt_term, rt_term2;
-    if constexpr (sizeof(F) == 8)
-    {
-        const F x = fast_rcp(D * fact);
-        rt_term = x * fact;
-        rt_term2 = ssa * x;
-    }
-    else
-    {
-        rt_term = F(1.) / D;
-        rt_term2 = ssa * rt_term / fact;
-    }
+    const F x = fast_rcp(D * fact);
+    const F rt_term = x * fact, rt_term2 = ssa * x;
     o.r_dif = rt_term * gamma2 * (F(1.) - exp_minus2ktau);
     o.t_dif = rt_term * F(2.) * k * exp_minusktau;
     o.t_noscat = exp_neg(-tau * mu0_inv);
