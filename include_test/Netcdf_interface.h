@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 #include "Netcdf_hdf5.h"
+#include "Netcdf_classic.h"
 
 enum class Netcdf_mode { Create, Read, Write };
 
@@ -247,10 +248,15 @@ class Netcdf_file : public Netcdf_handle
                 throw std::runtime_error(file_name + " is a NetCDF-4 file: this build has no HDF5 support");
 #endif
             }
+            if (rrx_cdf::version(file_name) != 0)                       // classic NetCDF (CDF-1 / CDF-2), read-only
+            {
+                rrx_cdf::read_file(file_name, dims, dim_order, vars, var_order);
+                return;
+            }
             std::ifstream f(file_name, std::ios::binary);
             if (!f) throw std::runtime_error("cannot open " + file_name);
             char magic[8]; f.read(magic, 8);
-            if (std::memcmp(magic, "RRXB1", 5) != 0) throw std::runtime_error(file_name + " is not an RRXB file");
+            if (std::memcmp(magic, "RRXB1", 5) != 0) throw std::runtime_error(file_name + " is neither NetCDF (classic or NetCDF-4) nor an RRXB container");
             auto get_u32 = [&]() { uint32_t v; f.read(reinterpret_cast<char*>(&v), 4); return v; };
             auto get_i64 = [&]() { int64_t v; f.read(reinterpret_cast<char*>(&v), 8); return v; };
             auto get_str = [&]() { std::string s(get_u32(), '\0'); f.read(&s[0], s.size()); return s; };

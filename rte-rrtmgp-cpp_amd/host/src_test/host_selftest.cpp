@@ -76,9 +76,20 @@ int rrx_host_netcdf_convert(const char* in_path, const char* out_path, const cha
     catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_convert: %s\n", e.what()); return 1; }
 }
 
-// String attribute of a variable of a NetCDF-4 file (e.g. "units"); returns the length, -1 when absent or on error.
+// String attribute of a variable of a NetCDF-4 or classic NetCDF file (e.g. "units"); returns the length, -1 when absent or on error.
 int rrx_host_netcdf_get_attr(const char* path, const char* var, const char* attr, char* buf, int buflen)
 {
+    if (rrx_cdf::version(path) != 0)                     // classic NetCDF
+    {
+        try
+        {
+            const std::string v = rrx_cdf::get_text_attr(path, var, attr);
+            if (v.empty() || int(v.size()) >= buflen) return -1;
+            std::memcpy(buf, v.c_str(), v.size() + 1);
+            return int(v.size());
+        }
+        catch (const std::exception& e) { std::fprintf(stderr, "rrx_host_netcdf_get_attr: %s\n", e.what()); return -1; }
+    }
 #ifdef RRX_HAVE_HDF5_HEADERS
     try
     {

@@ -236,3 +236,60 @@ def aerosol_optics_numpy(lut, aermr, rh, plev):
         od = (m * dpg)[None] * tab("mext")
         tau += od; ts += od * tab("ssa"); tsg += od * tab("ssa") * tab("g")
     return tau, ts / np.maximum(tau, eps), tsg / np.maximum(ts, eps)
+
+
+def write_netcdf_classic(path, dims, variables, version=1, record_dim=None, numrecs=0):
+    """A classic NetCDF file (CDF-1 / CDF-2) written by hand for the reader test: dims {name: length}, variables
+    {name: (array, [dim names])} with dtypes int8 / S1 (char) / int16 / int32 / float32 / float64; every variable gets a
+    `units` text attribute and the file one global attribute (the reader has to skip both)."""
+    import struct
+    TYPES = {"i1": 1, "S1": 2, "i2": 3, "i4": 4, "f4": 5, "f8": 6}
+    def pad(b): return b + b"\0"*((4 - len(b) % 4) % 4)
+    def name(s): return struct.pack(">I", len(s)) + pad(s.encode())
+    def att(n, text): return name(n) + struct.pack(">II", 2, len(text)) + pad(text.encode())
+    dnames = list(dims)
+    head = b"CDF" + bytes([version]) + struct.pack(">I", numrecs)
+    head += struct.pack(">II", 0x0A, len(dims))
+    for d in dnames:
+        head += name(d) + struct.pack(">I", 0 if d == record_dim else dims[d])
+    head += struct.pack(">II", 0x0C, 1) + att("title", "written by tests/cases.py")
+    infos = []
+    for n, (arr, dn) in variables.items():
+        arr = np.asarray(arr)
+        code = arr.dtype.kind + str(arr.dtype.itemsize) if arr.dtype.kind != "S" else "S1"
+        rec = bool(dn) and dn[0] == record_dim
+        per = int(np.prod([dims[d] for d in dn[1:]])) if rec else int(arr.size)
+        vsize = (per*arr.dtype.itemsize + 3)//4*4
+        infos.append(dict(name=n, arr=arr, dn=dn, type=TYPES[code], rec=rec, per=per, vsize=vsize))
+    nrec = sum(1 for i in infos if i["rec"])
+    if nrec == 1:                                         # single record variable: records are not padded
+        for i in infos:
+            if i["rec"]: i["rsize"] = i["per"]*i["arr"].dtype.itemsize
+    def var_header(i, begin):
+        h = name(i["name"]) + struct.pack(">I", len(i["dn"])) + b"".join(struct.pack(">I", dnames.index(d)) for d in i["dn"])
+        h += struct.pack(">II", 0x0C, 1) + att("units", "1e-6")
+        h += struct.pack(">II", i["type"], i["vsize"]) + (struct.pack(">I", begin) if version == 1 else struct.pack(">Q", begin))
+        return h
+    hlen = len(head) + 8 + sum(len(var_header(i, 0)) for i in infos)
+    pos = hlen
+    for i in infos:
+        if not i["rec"]: i["begin"] = pos; pos += i["vsize"]
+    recsize = sum(i["vsize"] for i in infos if i["rec"]) if nrec != 1 else [i["rsize"] for i in infos if i["rec"]][0]
+    for i in infos:
+        if i["rec"]: i["begin"] = pos; pos += i["vsize"] if nrec != 1 else 0
+    out = bytearray(head + struct.pack(">II", 0x0B, len(infos)) + b"".join(var_header(i, i["begin"]) for i in infos))
+    assert len(out) == hlen
+    end = max([i["begin"] + i["vsize"] for i in infos if not i["rec"]] + [hlen])
+    total = end + (numrecs*recsize if nrec else 0)
+    out += b"\0"*(total - len(out))
+    for i in infos:
+        be = i["arr"].astype(i["arr"].dtype.newbyteorder(">")).tobytes()
+        if not i["rec"]:
+            out[i["begin"]:i["begin"]+len(be)] = be
+        else:
+            rb = i["per"]*i["arr"].dtype.itemsize
+            for r in range(numrecs):
+                o = i["begin"] + r*recsize
+                out[o:o+rb] = be[r*rb:(r+1)*rb]
+    with open(path, "wb") as f:
+        f.write(bytes(out))

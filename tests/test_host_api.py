@@ -2,6 +2,8 @@
 every one of them and instantiates the class API the way the reference's drivers do), and the host library exports the
 driver entry point. No GPU calls."""
 import ctypes
+
+import pytest
 import os
 import subprocess
 import textwrap
@@ -95,3 +97,45 @@ def test_netcdf4_backend_roundtrip_and_real_file(tmp_path):
     assert set(v2) == set(v)
     for k in v:
         assert v[k][1] == v2[k][1] and np.array_equal(v[k][0], v2[k][0], equal_nan=True), k
+
+
+@pytest.mark.parametrize("version", [1, 2])
+@pytest.mark.parametrize("nrecvars", [0, 1, 2])
+def test_classic_netcdf_reader(version, nrecvars, tmp_path):
+    """Classic NetCDF (CDF-1 / CDF-2), the pre-HDF5 format some published data sets still use: every external type, fixed and
+    record variables (one record variable = unpadded records), attributes skipped; read through Netcdf_file and compared with
+    what was written (the file is produced by a few lines of struct.pack in tests/cases.py, not by a library)."""
+    import numpy as np
+    import cases
+    from rte_rrtmgp_cpp_amd import rrxio
+    rng = np.random.default_rng(5 + version + 10*nrecvars)
+    dims = dict(expt=3, site=5, level=7, string_len=4, one=1)
+    v = {"pres": (rng.uniform(1, 1e5, (5, 7)), ["site", "level"]),
+         "flag": (rng.integers(-100, 100, (5,), dtype=np.int8), ["site"]),
+         "small": (rng.integers(-30000, 30000, (7,), dtype=np.int16), ["level"]),
+         "count": (rng.integers(-2**30, 2**30, (5, 7), dtype=np.int32), ["site", "level"]),
+         "name": (np.frombuffer(b"h2o co2 o3  n2o ch4 ", dtype="S1").reshape(5, 4), ["site", "string_len"]),
+         "scalar": (np.array(1360.85), []),
+         "odd": (rng.uniform(0, 1, (1,)).astype(np.float32), ["one"])}
+    if nrecvars >= 1:
+        v["rld"] = (rng.uniform(0, 500, (3, 5, 7)).astype(np.float32), ["expt", "site", "level"])
+    if nrecvars >= 2:
+        v["t_sfc"] = (rng.uniform(250, 310, (3, 5)), ["expt", "site"])
+    path = str(tmp_path / "classic.nc")
+    cases.write_netcdf_classic(path, dims, v, version=version, record_dim="expt" if nrecvars else None, numrecs=3 if nrecvars else 0)
+    lib = _hostlib()
+    out = str(tmp_path / "classic.rrxb")
+    assert lib.rrx_host_netcdf_convert(path.encode(), out.encode(), b"rrxb") == 0
+    d2, v2 = rrxio.read(out)
+    for k, n in dims.items():
+        assert d2[k] == n, k
+    assert set(v2) == set(v)
+    for k, (arr, dn) in v.items():
+        got, gdn = v2[k]
+        assert gdn == dn, k
+        want = arr.view(np.int8) if arr.dtype.kind == "S" else (arr.astype(np.int32) if arr.dtype == np.int16 else arr)
+        assert got.dtype == want.dtype and np.array_equal(got, want), k
+    buf = ctypes.create_string_buffer(64)
+    assert lib.rrx_host_netcdf_get_attr(path.encode(), b"pres", b"units", buf, 64) == 4 and buf.value == b"1e-6"
+    assert lib.rrx_host_netcdf_get_attr(path.encode(), b"", b"title", buf, 64) > 0 and buf.value.startswith(b"written by")
+    assert lib.rrx_host_netcdf_get_attr(path.encode(), b"pres", b"nope", buf, 64) == -1

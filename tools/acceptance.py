@@ -55,7 +55,7 @@ def nc_read(path, scratch):
     """dims, {name: (array, dim names)} of a NetCDF-4 or RRXB file."""
     with open(path, "rb") as f:
         magic = f.read(4)
-    if magic == b"\x89HDF":
+    if magic == b"\x89HDF" or magic[:3] == b"CDF":        # NetCDF-4 or classic NetCDF: through the host library's readers
         tmp = os.path.join(scratch, "_read_%d.rrxb" % (abs(hash(path)) % 10**9))
         if hostlib().rrx_host_netcdf_convert(path.encode(), tmp.encode(), b"rrxb") != 0:
             raise RuntimeError("cannot read " + path)
