@@ -35,7 +35,20 @@ def rel_err(a, b, floor=1e-6):
     if b.size == 0:
         return 0.0
     scale = np.abs(b) + floor*np.max(np.abs(b)) + 1e-300
-    return float(np.max(np.abs(a - b) / scale))
+    err = float(np.max(np.abs(a - b) / scale))
+    _note_worst(err)
+    return err
+
+
+# worst relative error seen by each test (tests/conftest.py prints the table at the end of the run, so that a regression
+# inside a tolerance is visible in the log)
+WORST = {}
+
+
+def _note_worst(err):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    if test:
+        WORST[test] = max(WORST.get(test, 0.0), err)
 
 
 class Checker:

@@ -44,3 +44,18 @@ def hip_f64():
 def hip_f32():
     import rte_rrtmgp_cpp_amd as R
     return R.HipKernels(np.float32)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst relative error each parity test observed (cases.rel_err), fp64 and fp32 alike: a regression that stays inside its
+    tolerance still shows up here."""
+    try:
+        import cases
+    except Exception:
+        return
+    if not cases.WORST:
+        return
+    terminalreporter.write_line("")
+    terminalreporter.write_line("worst relative error per test (cases.rel_err):")
+    for test, err in sorted(cases.WORST.items()):
+        terminalreporter.write_line(f"  {err:9.2e}  {test.split('::', 1)[-1]}")
