@@ -608,7 +608,8 @@ def test_aerosol_optics_and_aerosol_sw_solve_match_oracle(dt, top_at_1, tmp_path
     # aerosols matter in this case: the clear+cloud solve differs visibly
     atm = pipeline.upload_atmosphere(hip, atm0)
     r0 = pipeline.solve_sw(hip, hip.upload_kdist(kd0), atm, cloud_lut=hip.upload_lut(cl), delta_cloud=True)
-    assert cases.rel_err(hip.to_numpy(r0["flux_dn_dir"]), out[hip]["flux_dn_dir"]) > 1e-3
+    a_, b_ = hip.to_numpy(r0["flux_dn_dir"]), out[hip]["flux_dn_dir"]          # (not a parity figure: kept out of cases.rel_err's table)
+    assert float(np.max(np.abs(a_ - b_)) / np.max(np.abs(b_))) > 1e-3
 
 
 def test_rccl_allgather_fluxes_c_abi(hip_f64):
