@@ -701,3 +701,31 @@ def test_pipelined_flux_gatherer_on_rccl_single_rank():
         assert torch.equal(out, 4.0*ref) and torch.equal(second.view(7, 141, 4096), 2.0*ref) and torch.equal(first.view(7, 141, 4096), 4.0*ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_keeps_its_contract():
+    """bench.py as the driver runs it (its own process, default workload, few steps): ONE JSON line with the contract's fields,
+    the roofline object (live HIP-event timing, committed PMC traffic) and the CPU baseline with its same-run parity check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-cols", "24"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "columns/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["columns_total"] == 16384
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"]/r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0.9*r["algorithmic_bytes_per_launch"]
+    assert abs(d["value"] - 16384*1e3/d["ms_per_step"]) / d["value"] < 1e-3 and d["finite"] is True
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["parity_max_rel"] <= 1e-6
+    assert abs(sum(s["ms"] for s in d["stages"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05   # the stages account for the step
