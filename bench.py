@@ -177,8 +177,8 @@ def local_atmosphere(args, nbnd, rank, world):
     from rte_rrtmgp_cpp_amd import synthetic, sharding
     ntot = global_columns(args, world)
     s, e = sharding.column_range(rank, world, ntot)
-    full = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234)
-    return (s, e), (full if world == 1 else sharding.shard_atmosphere(full, rank, world))
+    # only this rank's columns are built (column c is the same column whatever the number of ranks)
+    return (s, e), synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e))
 
 
 def main():

@@ -266,8 +266,23 @@ def _rcemip_profile(z):
     return p, q, T
 
 
-def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=False, clouds=False, z_top=70.e3, aerosols=False):
-    """RCEMIP analytic column replicated over ``ncol`` columns with a seeded +-1 K / +-5 % humidity perturbation."""
+def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=False, clouds=False, z_top=70.e3, aerosols=False,
+                    col_range=None):
+    """RCEMIP analytic column replicated over ``ncol`` columns with a seeded +-1 K / +-5 % humidity perturbation.
+    col_range = (start, stop): only those columns of the ncol-column atmosphere are built (a rank's share of a sharded job:
+    column c is the same column whatever the range), without ever holding the whole domain."""
+    if col_range is not None:
+        if clouds or aerosols:
+            raise ValueError("col_range is for the clear-sky benchmark atmosphere")
+        s_, e_ = col_range
+        rng = np.random.default_rng(seed)
+        dT_all = rng.uniform(-1.0, 1.0, size=ncol); dq_all = rng.uniform(0.95, 1.05, size=ncol)
+        return _make_atmosphere(e_ - s_, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, False, z_top, False,
+                                _perturbation=(dT_all[s_:e_], dq_all[s_:e_]))
+    return _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, aerosols)
+
+
+def _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, aerosols, _perturbation=None):
     rng = np.random.default_rng(seed)
     dz = z_top / nlay
     z = dz/2 + dz*np.arange(nlay)
@@ -281,6 +296,8 @@ def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=
 
     dT = rng.uniform(-1.0, 1.0, size=ncol)
     dq = rng.uniform(0.95, 1.05, size=ncol)
+    if _perturbation is not None:
+        dT, dq = (np.array(x, dtype=np.float64) for x in _perturbation)
     if os.environ.get("RRX_SYNTH_IDENTICAL_COLUMNS"):        # diagnostic only: the reference's own RCEMIP input
         dT[:] = 0.0; dq[:] = 1.0
 
