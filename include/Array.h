@@ -108,14 +108,14 @@ class Array_gpu
         Array_gpu(const Array<T,N>& a) : dims(a.dims), ncells(a.ncells), data_ptr(nullptr), strides(a.strides), offsets(a.offsets)
         {
             allocate();
-            if (ncells > 0) rrx_host::check(rrx_memcpy_h2d(data_ptr, a.ptr(), size_t(ncells)*sizeof(T)));
+            if (ncells > 0) rrx_host::check(rrx_memcpy_h2d_stream(data_ptr, a.ptr(), size_t(ncells)*sizeof(T), rrx_host::current_stream()));
         }
         Array_gpu(const Array_gpu<T,N>& a) : dims(a.dims), ncells(a.ncells), data_ptr(nullptr), strides(a.strides), offsets(a.offsets)
         {
             allocate();
             if (ncells > 0) { rrx_host::check(rrx_memcpy_d2d(data_ptr, a.data_ptr, size_t(ncells)*sizeof(T), rrx_host::current_stream())); }
         }
-        Array_gpu(Array_gpu<T,N>&& a) noexcept : dims(a.dims), ncells(a.ncells), data_ptr(a.data_ptr), strides(a.strides), offsets(a.offsets), owns(a.owns)
+        Array_gpu(Array_gpu<T,N>&& a) noexcept : dims(a.dims), ncells(a.ncells), data_ptr(a.data_ptr), strides(a.strides), offsets(a.offsets), owns(a.owns), alloc_stream(a.alloc_stream)
         { a.data_ptr = nullptr; a.ncells = 0; }
         // non-owning view of device memory managed elsewhere (reference: Array.h:476-486)
         Array_gpu(T* ptr, const std::array<int,N>& dims) : dims(dims), ncells(product<N>(dims)), data_ptr(ptr), strides(calc_strides<N>(dims)), offsets({}), owns(false) {}
@@ -134,6 +134,7 @@ class Array_gpu
             if (this == &a) return *this;
             release();
             dims = a.dims; ncells = a.ncells; data_ptr = a.data_ptr; strides = a.strides; offsets = a.offsets; owns = a.owns;
+            alloc_stream = a.alloc_stream;
             a.data_ptr = nullptr; a.ncells = 0;
             return *this;
         }
@@ -149,13 +150,13 @@ class Array_gpu
         void set_data(const Array<T,N>& a)
         {
             if (a.size() != ncells) throw std::runtime_error("set_data: size mismatch");
-            if (ncells > 0) rrx_host::check(rrx_memcpy_h2d(data_ptr, a.ptr(), size_t(ncells)*sizeof(T)));
+            if (ncells > 0) rrx_host::check(rrx_memcpy_h2d_stream(data_ptr, a.ptr(), size_t(ncells)*sizeof(T), rrx_host::current_stream()));
         }
         void fill(const T value)
         {
             if (ncells == 0) return;
             std::vector<T> h(ncells, value);          // rarely used outside setup code
-            rrx_host::check(rrx_memcpy_h2d(data_ptr, h.data(), size_t(ncells)*sizeof(T)));
+            rrx_host::check(rrx_memcpy_h2d_stream(data_ptr, h.data(), size_t(ncells)*sizeof(T), rrx_host::current_stream()));
         }
         T* ptr() { return data_ptr; }
         const T* ptr() const { return data_ptr; }
@@ -168,8 +169,7 @@ class Array_gpu
             int s = 0;
             for (int i=0; i<N; ++i) s += (idx[i] - offsets[i] - 1) * strides[i];
             T v;
-            rrx_host::check(rrx_synchronize(rrx_host::current_stream()));
-            rrx_host::check(rrx_memcpy_d2h(&v, data_ptr + s, sizeof(T)));
+            rrx_host::check(rrx_memcpy_d2h_stream(&v, data_ptr + s, sizeof(T), rrx_host::current_stream()));
             return v;
         }
 
@@ -193,13 +193,16 @@ class Array_gpu
         void dump(const std::string& name) const { Array<T,N> h(*this); h.dump(name); }
 
     private:
+        // stream-ordered: the block is usable by work enqueued on the calling thread's stream from here on, and goes back to
+        // the pool once the work enqueued on that stream before the release has run (no device-wide synchronisation)
         void allocate()
         {
-            if (ncells > 0) rrx_host::check(rrx_malloc(reinterpret_cast<void**>(&data_ptr), size_t(ncells)*sizeof(T)));
+            alloc_stream = rrx_host::current_stream();
+            if (ncells > 0) rrx_host::check(rrx_malloc_async(reinterpret_cast<void**>(&data_ptr), size_t(ncells)*sizeof(T), alloc_stream));
         }
         void release()
         {
-            if (data_ptr != nullptr && owns) rrx_free(data_ptr);
+            if (data_ptr != nullptr && owns) rrx_free_async(data_ptr, alloc_stream);
             data_ptr = nullptr;
         }
         std::array<int,N> dims;
@@ -208,6 +211,7 @@ class Array_gpu
         std::array<int,N> strides;
         std::array<int,N> offsets;
         bool owns = true;
+        void* alloc_stream = nullptr;
         template<typename, int> friend class Array;
 };
 
@@ -217,7 +221,7 @@ Array<T,N>::Array(const Array_gpu<T,N>& a) : dims(a.dims), ncells(a.ncells), dat
     if (ncells > 0)
     {
         rrx_host::check(rrx_synchronize(rrx_host::current_stream()));
-        rrx_host::check(rrx_memcpy_d2h(data.data(), a.ptr(), size_t(ncells)*sizeof(T)));
+        rrx_host::check(rrx_memcpy_d2h_stream(data.data(), a.ptr(), size_t(ncells)*sizeof(T), rrx_host::current_stream()));
     }
 }
 

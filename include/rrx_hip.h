@@ -37,6 +37,12 @@ int rrx_device_count(int* n);
 int rrx_set_device(int dev);
 int rrx_malloc(void** ptr, unsigned long long bytes);
 int rrx_free(void* ptr);
+/* stream-ordered twins (what Array_gpu uses): allocation from the device's default memory pool with the release threshold lifted,
+   so freed blocks are reused by the next solve and no call synchronises the device; the copies are enqueued on `stream` and awaited */
+int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream);
+int rrx_free_async(void* ptr, void* stream);
+int rrx_memcpy_h2d_stream(void* dst, const void* src, unsigned long long bytes, void* stream);
+int rrx_memcpy_d2h_stream(void* dst, const void* src, unsigned long long bytes, void* stream);
 int rrx_memcpy_h2d(void* dst, const void* src, unsigned long long bytes);
 int rrx_memcpy_d2h(void* dst, const void* src, unsigned long long bytes);
 int rrx_memcpy_d2d(void* dst, const void* src, unsigned long long bytes, void* stream);

@@ -431,6 +431,39 @@ int rrx_device_count(int* n) { RRX_HIP_OK(hipGetDeviceCount(n), "rrx_device_coun
 int rrx_set_device(int dev) { RRX_HIP_OK(hipSetDevice(dev), "rrx_set_device"); return 0; }
 int rrx_malloc(void** ptr, unsigned long long bytes) { RRX_HIP_OK(hipMalloc(ptr, bytes ? bytes : 1), "rrx_malloc"); return 0; }
 int rrx_free(void* ptr) { RRX_HIP_OK(hipFree(ptr), "rrx_free"); return 0; }
+// Stream-ordered allocation (the reference's memory-pool strategies, src_cuda/mem_pool_gpu.cu, in one line of HIP): memory comes
+// from the device's default pool, whose release threshold is lifted once, so blocks freed by one solve are reused by the next
+// without going back to the driver -- and without hipFree's device-wide synchronisation.
+int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream)
+{
+    static thread_local int configured_device = -1;
+    int dev = 0;
+    RRX_HIP_OK(hipGetDevice(&dev), "rrx_malloc_async");
+    if (dev != configured_device)
+    {
+        hipMemPool_t pool;
+        RRX_HIP_OK(hipDeviceGetDefaultMemPool(&pool, dev), "rrx_malloc_async");
+        unsigned long long keep = ~0ull;
+        RRX_HIP_OK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep), "rrx_malloc_async");
+        configured_device = dev;
+    }
+    RRX_HIP_OK(hipMallocAsync(ptr, bytes ? bytes : 1, static_cast<hipStream_t>(stream)), "rrx_malloc_async");
+    return 0;
+}
+int rrx_free_async(void* ptr, void* stream) { RRX_HIP_OK(hipFreeAsync(ptr, static_cast<hipStream_t>(stream)), "rrx_free_async"); return 0; }
+// host <-> device copies enqueued on `stream` and awaited (the host buffer is consumed / filled when the call returns)
+int rrx_memcpy_h2d_stream(void* dst, const void* src, unsigned long long bytes, void* stream)
+{
+    RRX_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)), "rrx_memcpy_h2d_stream");
+    RRX_HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "rrx_memcpy_h2d_stream");
+    return 0;
+}
+int rrx_memcpy_d2h_stream(void* dst, const void* src, unsigned long long bytes, void* stream)
+{
+    RRX_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)), "rrx_memcpy_d2h_stream");
+    RRX_HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "rrx_memcpy_d2h_stream");
+    return 0;
+}
 int rrx_memcpy_h2d(void* dst, const void* src, unsigned long long bytes) { RRX_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "rrx_memcpy_h2d"); return 0; }
 int rrx_memcpy_d2h(void* dst, const void* src, unsigned long long bytes) { RRX_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "rrx_memcpy_d2h"); return 0; }
 int rrx_memcpy_d2d(void* dst, const void* src, unsigned long long bytes, void* stream) { RRX_HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)), "rrx_memcpy_d2d"); return 0; }
