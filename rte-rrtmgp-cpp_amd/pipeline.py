@@ -215,10 +215,10 @@ class ResidentSolver:
         self.fluxes = e((7, nlay+1, ncol))
         self.weights = be.asarray(np.ascontiguousarray(GAUSS_WTS[0, :1]))
         self.gauss_Ds = be.asarray(GAUSS_DS)
-        self.secants = be.lw_secants_array(ncol, ng_l, 1, MAX_GAUSS_PTS, self.gauss_Ds)
-        self.sfc_emis_gpt = be.expand_and_transpose(kd_lw.band_lims_gpt, atm.emis_sfc, ng_l)
-        self.alb_dir = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dir, ng_s)
-        self.alb_dif = be.expand_and_transpose(kd_sw.band_lims_gpt, atm.sfc_alb_dif, ng_s)
+        # secants and the band -> g-point expansion of emissivity / albedos: buffers allocated once, the launches themselves are
+        # part of every step (rte_lw / rte_sw of the reference run them per solve: src_cuda/Rte_lw.cu:70-110, Rte_sw.cu:57-100)
+        self.secants = e((1, ng_l, ncol))
+        self.sfc_emis_gpt = e((ng_l, ncol)); self.alb_dir = e((ng_s, ncol)); self.alb_dif = e((ng_s, ncol))
         self.events = None
         self.col_dry2 = None
 
@@ -278,6 +278,8 @@ class ResidentSolver:
                     be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), out=srcs)
                 mark("lw_planck", True)
                 mark("lw_solver")
+                be._c("lw_secants_array", ncol, kd.ngpt, 1, MAX_GAUSS_PTS, self.gauss_Ds, self.secants)
+                be._c("expand_and_transpose", ncol, kd.nbnd, kd.band_lims_gpt, atm.emis_sfc, self.sfc_emis_gpt)
                 if self.lite:
                     be.lw_solver_noscat_fractions(atm.top_at_1, kd, self.secants, self.weights, buf["tau"], buf, self.sfc_emis_gpt,
                                                   flux_up=F[0], flux_dn=F[1])
@@ -305,6 +307,8 @@ class ResidentSolver:
                 be.scaling_to_subset(toa, atm.tsi_scaling)
                 mark("sw_gas_optics", True)
                 mark("sw_solver")
+                be._c("expand_and_transpose", ncol, kd.nbnd, kd.band_lims_gpt, atm.sfc_alb_dir, self.alb_dir)
+                be._c("expand_and_transpose", ncol, kd.nbnd, kd.band_lims_gpt, atm.sfc_alb_dif, self.alb_dif)
                 if self.do_broadband:
                     be._c("sw_solver_2stream", ncol, nlay, kd.ngpt, BoolArg(atm.top_at_1), buf["tau"], buf["ssa"], gbuf, atm.mu0,
                           self.alb_dir, self.alb_dif, toa, None, None, None, BoolArg(False), None,
