@@ -53,6 +53,12 @@ namespace rrx
     __device__ __forceinline__ double shfl(const double v, const int src_lane) { return __shfl(v, src_lane, WAVE); }
 
     // ---- vector-of-columns helpers: V consecutive columns handled by one lane ----
+#ifndef RRX_NT_LOADS
+#define RRX_NT_LOADS 0    // A/B: non-temporal loads of the solvers' cell arrays
+#endif
+#ifndef RRX_NT_STORES
+#define RRX_NT_STORES 0   // A/B: non-temporal stores of the solvers' flux arrays
+#endif
     template<typename F, int V> struct Vec { F v[V]; };
 
     // V consecutive columns starting at p. The launchers only pick V > 1 when ncol % V == 0, so a lane's V columns
@@ -62,11 +68,21 @@ namespace rrx
     {
         Vec<F,V> r;
         if constexpr (V == 1)
+        {
+#if RRX_NT_LOADS
+            r.v[0] = __builtin_nontemporal_load(p);
+#else
             r.v[0] = p[0];
+#endif
+        }
         else
         {
             typedef F vecT __attribute__((ext_vector_type(V)));
+#if RRX_NT_LOADS
+            const vecT t = __builtin_nontemporal_load(reinterpret_cast<const vecT*>(p));
+#else
             const vecT t = *reinterpret_cast<const vecT*>(p);
+#endif
             #pragma unroll
             for (int i=0; i<V; ++i) r.v[i] = t[i];
         }
@@ -77,14 +93,24 @@ namespace rrx
     __device__ __forceinline__ void store_cols(F* __restrict__ p, const Vec<F,V>& r)
     {
         if constexpr (V == 1)
+        {
+#if RRX_NT_STORES
+            __builtin_nontemporal_store(r.v[0], p);
+#else
             p[0] = r.v[0];
+#endif
+        }
         else
         {
             typedef F vecT __attribute__((ext_vector_type(V)));
             vecT t;
             #pragma unroll
             for (int i=0; i<V; ++i) t[i] = r.v[i];
+#if RRX_NT_STORES
+            __builtin_nontemporal_store(t, reinterpret_cast<vecT*>(p));
+#else
             *reinterpret_cast<vecT*>(p) = t;
+#endif
         }
     }
 

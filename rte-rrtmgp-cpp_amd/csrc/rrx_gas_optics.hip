@@ -18,6 +18,18 @@
 
 namespace
 {
+#ifndef RRX_GW_NT
+#define RRX_GW_NT 1       // the cell arrays are written once and far exceed the caches: non-temporal stores keep them from evicting the LUTs
+#endif
+template<typename F> __device__ __forceinline__ void stream_store(F* p, const F v)
+{
+#if RRX_GW_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 using namespace rrx;
 
 constexpr int GCH = 16;          // g-points per register chunk
@@ -603,15 +615,15 @@ tau_absorption_kernel(
                 }
                 else if constexpr (MODE == 2)
                 {
-                    tau[o] = t[u];
+                    stream_store(tau + o, t[u]);
                 }
                 else
                 {
                     const F ray = ray_fac * (fn0*rv[u][0] + fn1*rv[u][1] + fn2*rv[u][2] + fn3*rv[u][3]);
                     const F tt = t[u] + ray;
-                    tau[o] = tt;
-                    ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
-                    if (g != nullptr) g[o] = F(0.);
+                    stream_store(tau + o, tt);
+                    stream_store(ssa + o, (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.));
+                    if (g != nullptr) stream_store(g + o, F(0.));
                 }
             }
         }
@@ -972,10 +984,10 @@ planck_source_kernel(
             if (active)
             {
                 const F pfrac = pf[(u*(PL+1) + ly+1)*64 + tx];
-                lay_src[idx + size_t(ig)*ncl] = pfrac * b_lay;
+                stream_store(lay_src + idx + size_t(ig)*ncl, pfrac * b_lay);
                 F lev_val = pfrac * b_lev;
                 if (has_prev) lev_val = sqrt(pfrac * pf[(u*(PL+1) + ly)*64 + tx]) * b_lev;
-                lev_src[idx + size_t(ig)*ncv] = lev_val;
+                stream_store(lev_src + idx + size_t(ig)*ncv, lev_val);
                 if (is_last) lev_src[idx + ncol + size_t(ig)*ncv] = pfrac * b_levp;
                 if (is_sfc)
                 {
@@ -1092,7 +1104,7 @@ planck_fraction_kernel(
             {
                 const F pfrac = (ci.fm[0]*v[u][0] + ci.fm[1]*v[u][1] + ci.fm[2]*v[u][2] + ci.fm[3]*v[u][3])
                               + (ci.fm[4]*v[u][4] + ci.fm[5]*v[u][5] + ci.fm[6]*v[u][6] + ci.fm[7]*v[u][7]);
-                pfrac_out[idx + size_t(g)*ncl] = pfrac;
+                stream_store(pfrac_out + idx + size_t(g)*ncl, pfrac);
                 const int ibnd = gpoint_bands[g] - 1;
                 if (ibnd != cur_bnd)
                 {
@@ -1569,16 +1581,16 @@ gas_window_kernel(
                 const size_t o = idx + size_t(ig)*ncl;
                 if constexpr (MODE == 2)
                 {
-                    if (active) tau[o] = t[u];
+                    if (active) stream_store(tau + o, t[u]);
                 }
                 else
                 {
                     const F tt = t[u] + ray[u];
                     if (active)
                     {
-                        tau[o] = tt;
-                        ssa[o] = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
-                        if (g != nullptr) g[o] = F(0.);
+                        stream_store(tau + o, tt);
+                        stream_store(ssa + o, (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.));
+                        if (g != nullptr) stream_store(g + o, F(0.));
                     }
                 }
                 if constexpr (PF)
@@ -1606,7 +1618,7 @@ gas_window_kernel(
                     }
                     if (active)
                     {
-                        pa.pfrac[o] = pfrac;
+                        stream_store(pa.pfrac + o, pfrac);
                         if (is_sfc)
                         {
                             pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
