@@ -343,7 +343,10 @@ lw_noscat_scan_kernel(
 #ifndef RRX_LW_LACC
 #define RRX_LW_LACC 1
 #endif
-template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = 2>
+#ifndef RRX_LW_EV
+#define RRX_LW_EV 2
+#endif
+template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = RRX_LW_EV>
 __global__ void __launch_bounds__(256, 2)
 lw_noscat_bb_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
