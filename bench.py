@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="wait for each all-gather before the next solve starts (A/B of the pipelined exchange)")
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
+    ap.add_argument("--allsky", action="store_true",
+                    help="BASELINE's all-sky flow (C5): cloud optics added by band after the gas optics, delta-scaled in SW; not the headline workload")
     args = ap.parse_args()
     args.broadband = (args.flux_mode == "broadband" or args.broadband) and not args.per_gpoint
 
@@ -247,9 +249,16 @@ def main():
     # rank r owns the contiguous column range sharding.column_range(r, world, ntot) of ONE global atmosphere
     ntot = global_columns(args, world)
     (col_s, col_e), atm0 = local_atmosphere(args, nbnd, rank, world)
+    cloud_luts = None
+    if args.allsky:
+        from rte_rrtmgp_cpp_amd import sharding as _sh
+        full = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, clouds=True)
+        atm0 = full if world == 1 else _sh.shard_atmosphere(full, rank, world)
+        cast = lambda lut: be.upload_lut({k: (v.astype(np_dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
+        cloud_luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
     ncol_local = col_e - col_s
     atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
-    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap)
+    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts)
     do_gather = world > 1 and not args.no_gather
     gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
 
@@ -302,7 +311,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C4 synthetic {ncol_local} columns/GPU ({ntot} in total) x {args.nlay} layers x {args.ngpt} g-points, "
-                                   f"LW+SW clear-sky, RCEMIP profile, synthetic k-distribution (real shapes)",
+                                   f"LW+SW {'all-sky (cloud optics, delta-scaled in SW)' if args.allsky else 'clear-sky'}, RCEMIP profile, synthetic k-distribution (real shapes)",
                        "columns_per_gpu": ncol_local, "columns_total": ntot, "nlay": args.nlay, "ngpt": args.ngpt,
                        "flux_mode": "broadband (do_broadband solvers, g-point sums on chip)" if args.broadband
                                     else "per-g-point fluxes + sum_broadband",
@@ -314,7 +323,7 @@ def main():
             "stages": kernels,
             "finite": finite,
         }
-        if world == 1 and args.cpu_cols > 0:
+        if world == 1 and args.cpu_cols > 0 and not args.allsky:      # (the CPU sample is the clear-sky headline workload)
             out["cpu_baseline"] = cpu_baseline(args, kd_lw0, kd_sw0, be)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -191,6 +191,23 @@ int rrx_gas_optics_lw_direct##SFX( \
         const int* flavor, const F* press_ref_log, const F* temp_ref, \
         F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
         const F* play, const F* tlay, const F* col_gas, F* tau, void* stream); \
+/* rrx_gas_optics_lw_direct with optical properties given by band (clouds, aerosols: cld_* are (ncol,nlay,nbnd) arrays, bands delimited by \
+   band_lims_gpt) added where the gas optics is stored -- increment_1scalar_by_1scalar_bybnd folded into the producer, same \
+   arithmetic and bits, without reading and re-writing the g-point arrays; cld_tau = NULL: the plain entry */ \
+int rrx_gas_optics_lw_direct_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, F* tau, const F* cld_tau, void* stream); \
 int rrx_gas_optics_sw_direct##SFX( \
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
         int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
@@ -206,6 +223,24 @@ int rrx_gas_optics_sw_direct##SFX( \
         F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
         const F* play, const F* tlay, const F* col_gas, const F* col_dry, const F* krayl, \
         F* tau, F* ssa, F* g, void* stream); \
+/* rrx_gas_optics_sw_direct with optical properties given by band (clouds, aerosols: cld_* are (ncol,nlay,nbnd) arrays, bands delimited by \
+   band_lims_gpt) added where the gas optics is stored -- increment_2stream_by_2stream_bybnd folded into the producer, same \
+   arithmetic and bits, without reading and re-writing the g-point arrays (g must be given); cld_tau = NULL: the plain entry */ \
+int rrx_gas_optics_sw_direct_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry, const F* krayl, \
+        F* tau, F* ssa, F* g, const F* cld_tau, const F* cld_ssa, const F* cld_g, void* stream); \
 int rrx_planck_source_direct##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
         const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
@@ -246,6 +281,25 @@ int rrx_gas_optics_lw_fractions##SFX( \
         const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
         const F* pfracin, F totplnk_delta, const F* totplnk, \
         F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream); \
+/* rrx_gas_optics_lw_fractions with optical properties given by band (clouds, aerosols: cld_* are (ncol,nlay,nbnd) arrays, bands delimited by \
+   band_lims_gpt) added where the gas optics is stored -- increment_1scalar_by_1scalar_bybnd folded into the producer, same \
+   arithmetic and bits, without reading and re-writing the g-point arrays; cld_tau = NULL: the plain entry */ \
+int rrx_gas_optics_lw_fractions_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, const int* gpoint_bands, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const F* pfracin, F totplnk_delta, const F* totplnk, \
+        F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, const F* cld_tau, void* stream); \
 int rrx_planck_sources_from_fractions##SFX(int ncol, int nlay, int ngpt, const int* gpoint_bands, const F* pfrac, const F* blay, \
         const F* blev, F* lay_src, F* lev_src, void* stream); \
 int rrx_lw_solver_noscat_fractions##SFX( \

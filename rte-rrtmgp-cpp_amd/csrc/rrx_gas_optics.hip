@@ -117,7 +117,22 @@ struct InterpArgs
 {
     int ngas; const int* flavor; const F* press_ref_log; const F* temp_ref;
     F press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log; const F* vmr_ref;
+    // all-sky: optical properties by band (nbnd, nlay, ncol) -- clouds, aerosols -- added to the gas optics where it is stored
+    // (increment_*_by_*_bybnd of optical_props_kernels.cu:31-139 folded into the producer); cld_lims = band_lims_gpt (2, nbnd)
+    const F* cld_tau = nullptr; const F* cld_ssa = nullptr; const F* cld_g = nullptr; const int* cld_lims = nullptr;
 };
+
+// the arithmetic of inc_2stream_by_2stream_bybnd for one g-point of a cell (rrx_misc.hip:inc_2str, same order of operations)
+template<typename F>
+__device__ __forceinline__ void add_by_band_2str(F& tau1, F& ssa1, F& g1, const F tau2, const F ssa2, const F g2)
+{
+    const F eps = Lim<F>::tiny()*F(3.);
+    const F tau12 = tau1 + tau2;
+    const F tauscat12 = (tau1 * ssa1) + (tau2 * ssa2);
+    g1 = ((tau1 * ssa1 * g1) + (tau2 * ssa2 * g2)) / max(tauscat12, eps);
+    ssa1 = tauscat12 / max(eps, tau12);
+    tau1 = tau12;
+}
 
 template<typename F>
 struct CellState { int jt, jp_raw, itropo; F ftemp, fpress; };
@@ -249,7 +264,7 @@ __device__ __forceinline__ Pair<F> ld2(const F* __restrict__ base, const unsigne
 // A minor interval uses the flavor of its first g-point, exactly as the reference kernel (:533).
 // DIRECT: the interpolation state is computed in the kernel from (play, tlay, col_gas) -- InterpArgs -- and the arrays
 // tropo / col_mix / fmajor / fminor / jeta / jtemp / jpress are not touched (may be null).
-template<typename F, int MODE, bool DIRECT = false>
+template<typename F, int MODE, bool DIRECT = false, bool CLD = false>
 __global__ void __launch_bounds__(256, 2)
 tau_absorption_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
@@ -448,6 +463,7 @@ tau_absorption_kernel(
     constexpr int G = (sizeof(F) == 8 && MODE == 1) ? 2 : 4;
     constexpr int NPRE = (sizeof(F) == 8) ? ((MODE == 1) ? 0 : 2) : 1;
 #endif
+    [[maybe_unused]] int cb = 0;                 // CLD: band (0-based) of the g-point being stored; g-points ascend within a pass
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
     {
         int igs[G];
@@ -615,15 +631,32 @@ tau_absorption_kernel(
                 }
                 else if constexpr (MODE == 2)
                 {
-                    stream_store(tau + o, t[u]);
+                    if constexpr (CLD)
+                    {
+                        while (ig0 + u + 1 > ia.cld_lims[2*cb+1]) ++cb;
+                        stream_store(tau + o, t[u] + ia.cld_tau[idx + size_t(cb)*ncl]);
+                    }
+                    else stream_store(tau + o, t[u]);
                 }
                 else
                 {
                     const F ray = ray_fac * (fn0*rv[u][0] + fn1*rv[u][1] + fn2*rv[u][2] + fn3*rv[u][3]);
-                    const F tt = t[u] + ray;
-                    stream_store(tau + o, tt);
-                    stream_store(ssa + o, (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.));
-                    if (g != nullptr) stream_store(g + o, F(0.));
+                    F tt = t[u] + ray;
+                    F ww = (tt > F(2.)*Lim<F>::eps()) ? ray / tt : F(0.);
+                    if constexpr (CLD)
+                    {
+                        while (ig0 + u + 1 > ia.cld_lims[2*cb+1]) ++cb;
+                        const size_t b = idx + size_t(cb)*ncl;
+                        F gg = F(0.);
+                        add_by_band_2str(tt, ww, gg, ia.cld_tau[b], ia.cld_ssa[b], ia.cld_g[b]);
+                        stream_store(tau + o, tt); stream_store(ssa + o, ww); stream_store(g + o, gg);
+                    }
+                    else
+                    {
+                        stream_store(tau + o, tt);
+                        stream_store(ssa + o, ww);
+                        if (g != nullptr) stream_store(g + o, F(0.));
+                    }
                 }
             }
         }
@@ -1192,7 +1225,7 @@ size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int mode, cons
 #ifndef RRX_GW_MINW
 #define RRX_GW_MINW 3
 #endif
-template<typename F, int MODE, bool PF>
+template<typename F, int MODE, bool PF, bool CLD = false>
 __global__ void __launch_bounds__(256, RRX_GW_MINW)
 gas_window_kernel(
         const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
@@ -1365,6 +1398,7 @@ gas_window_kernel(
     }
 
     int cur_flav = -1, je_lo = 1;
+    [[maybe_unused]] int cb = 0;                 // CLD: band (0-based) of the g-point being stored (g-points ascend over the chunk loop)
     F fm[8], cm[2], fn[4]; int je[2] = {1, 1};
     #pragma unroll
     for (int i=0; i<8; ++i) fm[i] = F(0.);
@@ -1579,17 +1613,27 @@ gas_window_kernel(
             {
                 const int gi = gi0 + u, ig = c0 + gi;
                 const size_t o = idx + size_t(ig)*ncl;
+                if constexpr (CLD) { while (ig + 1 > ia.cld_lims[2*cb+1]) ++cb; }
                 if constexpr (MODE == 2)
                 {
-                    if (active) stream_store(tau + o, t[u]);
+                    if constexpr (CLD) { if (active) stream_store(tau + o, t[u] + ia.cld_tau[idx + size_t(cb)*ncl]); }
+                    else if (active) stream_store(tau + o, t[u]);
                 }
                 else
                 {
-                    const F tt = t[u] + ray[u];
-                    if (active)
+                    F tt = t[u] + ray[u];
+                    F ww = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
+                    if constexpr (CLD)
+                    {
+                        const size_t b = idx + size_t(cb)*ncl;
+                        F gg = F(0.);
+                        add_by_band_2str(tt, ww, gg, ia.cld_tau[b], ia.cld_ssa[b], ia.cld_g[b]);
+                        if (active) { stream_store(tau + o, tt); stream_store(ssa + o, ww); stream_store(g + o, gg); }
+                    }
+                    else if (active)
                     {
                         stream_store(tau + o, tt);
-                        stream_store(ssa + o, (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.));
+                        stream_store(ssa + o, ww);
                         if (g != nullptr) stream_store(g + o, F(0.));
                     }
                 }
@@ -1714,27 +1758,31 @@ int gas_optics_lw_fractions_impl(
         todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
         const PlanckArgs<F> pa{pfracin, tlev, tsfc, sfc_lay, nPlanckTemp, gpoint_bands, totplnk_delta, totplnk, pfrac, blay, blev, sfc_src, sfc_src_jac};
-        gas_window_kernel<F,2,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(
-                ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
-                kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
-                minor_scales_with_density_lower, minor_scales_with_density_upper,
-                scale_by_complement_lower, scale_by_complement_upper,
-                idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
-                kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia,
-                tau, (F*)nullptr, (F*)nullptr, pa, todo);
+#define RRX_GW_PF_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
+                kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+                minor_scales_with_density_lower, minor_scales_with_density_upper, \
+                scale_by_complement_lower, scale_by_complement_upper, \
+                idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
+                kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia, \
+                tau, (F*)nullptr, (F*)nullptr, pa, todo
+        if (ia.cld_tau != nullptr) gas_window_kernel<F,2,true,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
+        else gas_window_kernel<F,2,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
+#undef RRX_GW_PF_ARGS
         gas_window_stats("lw + fractions", todo, nblk*nz, st);
     }
     const dim3 g2 = windowed ? dim3(nblk*nz) : grid;
-    tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(
-            ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
-            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
-            minor_scales_with_density_lower, minor_scales_with_density_upper,
-            scale_by_complement_lower, scale_by_complement_upper,
-            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
-            kminor_start_lower, kminor_start_upper,
-            (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr,
-            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr,
-            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x), nblk, nz);
+#define RRX_TA_PF_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, \
+            scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
+            kminor_start_lower, kminor_start_upper, \
+            (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr, \
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr, \
+            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x), nblk, nz
+    if (ia.cld_tau != nullptr) tau_absorption_kernel<F,2,true,true><<<g2, block, lds, st>>>(RRX_TA_PF_ARGS);
+    else tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(RRX_TA_PF_ARGS);
+#undef RRX_TA_PF_ARGS
     planck_fraction_kernel<F><<<g2, block, size_t(2)*ngpt*sizeof(int), st>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin,
             totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x), nblk, nz);
@@ -1779,36 +1827,56 @@ int tau_absorption_impl(
             const int nz = gas_window_parts(nblk, nchunk);
             int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
-            gas_window_kernel<F,MODE,false><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(
-                    ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
-                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
-                    minor_scales_with_density_lower, minor_scales_with_density_upper,
-                    scale_by_complement_lower, scale_by_complement_upper,
-                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
-                    kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g,
-                    PlanckArgs<F>(), todo);
+#define RRX_GW_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
+                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+                    minor_scales_with_density_lower, minor_scales_with_density_upper, \
+                    scale_by_complement_lower, scale_by_complement_upper, \
+                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
+                    kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g, \
+                    PlanckArgs<F>(), todo
+#define RRX_TA_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
+                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+                    minor_scales_with_density_lower, minor_scales_with_density_upper, \
+                    scale_by_complement_lower, scale_by_complement_upper, \
+                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
+                    kminor_start_lower, kminor_start_upper, \
+                    tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl, \
+                    tau, ssa, g, ia, todo, int(grid.x), nblk, nz
+            const bool cld = DIRECT && MODE != 0 && ia.cld_tau != nullptr;
+            if constexpr (DIRECT && MODE != 0)
+            {
+                if (cld) gas_window_kernel<F,MODE,false,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
+            }
+            if (!cld) gas_window_kernel<F,MODE,false><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
             gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk*nz, st);
-            tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk*nz), block, lds, st>>>(
-                    ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
-                    kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
-                    minor_scales_with_density_lower, minor_scales_with_density_upper,
-                    scale_by_complement_lower, scale_by_complement_upper,
-                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
-                    kminor_start_lower, kminor_start_upper,
-                    tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
-                    tau, ssa, g, ia, todo, int(grid.x), nblk, nz);
+            if constexpr (DIRECT && MODE != 0)
+            {
+                if (cld) tau_absorption_kernel<F,MODE,DIRECT,true><<<dim3(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
+            }
+            if (!cld) tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
+#undef RRX_GW_ARGS
+#undef RRX_TA_ARGS
             return check_launch(name);
         }
     }
-    tau_absorption_kernel<F,MODE,DIRECT><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(
-            ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor,
-            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
-            minor_scales_with_density_lower, minor_scales_with_density_upper,
-            scale_by_complement_lower, scale_by_complement_upper,
-            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
-            kminor_start_lower, kminor_start_upper,
-            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl,
-            tau, ssa, g, ia);
+#define RRX_TA_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, \
+            scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
+            kminor_start_lower, kminor_start_upper, \
+            tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl, \
+            tau, ssa, g, ia
+    if constexpr (DIRECT && MODE != 0)
+    {
+        if (ia.cld_tau != nullptr)
+        {
+            tau_absorption_kernel<F,MODE,DIRECT,true><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(RRX_TA_ARGS);
+            return check_launch(name);
+        }
+    }
+    tau_absorption_kernel<F,MODE,DIRECT><<<grid, block, lds, static_cast<hipStream_t>(stream)>>>(RRX_TA_ARGS);
+#undef RRX_TA_ARGS
     RRX_CATCH(name)
 }
 }  // namespace
@@ -1927,6 +1995,32 @@ int rrx_gas_optics_lw_direct##SFX( \
             (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr, \
             tau, (F*)nullptr, (F*)nullptr, stream, "rrx_gas_optics_lw_direct", ia); \
 } \
+int rrx_gas_optics_lw_direct_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, F* tau, const F* cld_tau, void* stream) \
+{ \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref, \
+            cld_tau, (const F*)nullptr, (const F*)nullptr, band_lims_gpt}; \
+    return tau_absorption_impl<F,2,true>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            (const RrxBool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr, \
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr, \
+            tau, (F*)nullptr, (F*)nullptr, stream, "rrx_gas_optics_lw_direct_allsky", ia); \
+} \
 int rrx_gas_optics_sw_direct##SFX( \
         int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
         int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
@@ -1952,6 +2046,34 @@ int rrx_gas_optics_sw_direct##SFX( \
             (const RrxBool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, col_dry, \
             (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, krayl, \
             tau, ssa, g, stream, "rrx_gas_optics_sw_direct", ia); \
+} \
+int rrx_gas_optics_sw_direct_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* col_gas, const F* col_dry, const F* krayl, \
+        F* tau, F* ssa, F* g, const F* cld_tau, const F* cld_ssa, const F* cld_g, void* stream) \
+{ \
+    if (cld_tau != nullptr && (cld_ssa == nullptr || cld_g == nullptr || g == nullptr)) { rrx::set_error("rrx_gas_optics_sw_direct_allsky: by-band ssa, g and the g output are needed with by-band tau"); return 1; } \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref, \
+            cld_tau, cld_ssa, cld_g, band_lims_gpt}; \
+    return tau_absorption_impl<F,1,true>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, \
+            nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, \
+            kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            (const RrxBool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, col_dry, \
+            (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, krayl, \
+            tau, ssa, g, stream, "rrx_gas_optics_sw_direct_allsky", ia); \
 } \
 int rrx_planck_source_direct##SFX( \
         int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
@@ -1991,6 +2113,32 @@ int rrx_gas_optics_lw_fractions##SFX( \
 { \
     (void)nminorklower; (void)nminorkupper; (void)band_lims_gpt; \
     const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref}; \
+    return gas_optics_lw_fractions_impl<F>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, nPlanckTemp, nminorlower, nminorupper, idx_h2o, \
+            gpoint_flavor, gpoint_bands, kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
+            minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \
+            idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, \
+            ia, play, tlay, tlev, tsfc, sfc_lay, col_gas, pfracin, totplnk_delta, totplnk, tau, pfrac, blay, blev, sfc_src, sfc_src_jac, stream); \
+} \
+int rrx_gas_optics_lw_fractions_allsky##SFX( \
+        int ncol, int nlay, int nband, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nPlanckTemp, \
+        int nminorlower, int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, \
+        const int* gpoint_flavor, const int* band_lims_gpt, const int* gpoint_bands, \
+        const F* kmajor, const F* kminor_lower, const F* kminor_upper, \
+        const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper, \
+        const RrxBool* minor_scales_with_density_lower, const RrxBool* minor_scales_with_density_upper, \
+        const RrxBool* scale_by_complement_lower, const RrxBool* scale_by_complement_upper, \
+        const int* idx_minor_lower, const int* idx_minor_upper, \
+        const int* idx_minor_scaling_lower, const int* idx_minor_scaling_upper, \
+        const int* kminor_start_lower, const int* kminor_start_upper, \
+        const int* flavor, const F* press_ref_log, const F* temp_ref, \
+        F press_ref_log_delta, F temp_ref_min, F temp_ref_delta, F press_ref_trop_log, const F* vmr_ref, \
+        const F* play, const F* tlay, const F* tlev, const F* tsfc, int sfc_lay, const F* col_gas, \
+        const F* pfracin, F totplnk_delta, const F* totplnk, \
+        F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, const F* cld_tau, void* stream) \
+{ \
+    (void)nminorklower; (void)nminorkupper; \
+    const InterpArgs<F> ia{ngas, flavor, press_ref_log, temp_ref, press_ref_log_delta, temp_ref_min, temp_ref_delta, press_ref_trop_log, vmr_ref, \
+            cld_tau, (const F*)nullptr, (const F*)nullptr, band_lims_gpt}; \
     return gas_optics_lw_fractions_impl<F>(ncol, nlay, nband, ngpt, ngas, nflav, neta, npres, ntemp, nPlanckTemp, nminorlower, nminorupper, idx_h2o, \
             gpoint_flavor, gpoint_bands, kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
             minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper, \

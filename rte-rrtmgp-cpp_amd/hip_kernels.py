@@ -205,13 +205,22 @@ class HipKernels:
                 kd.idx_minor_lower, kd.idx_minor_upper, kd.idx_minor_scaling_lower, kd.idx_minor_scaling_upper,
                 kd.kminor_start_lower, kd.kminor_start_upper)
 
-    def gas_optics_lw_direct(self, kd, play, tlay, col_gas, tau):
-        self._c("gas_optics_lw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, tau)
+    def gas_optics_lw_direct(self, kd, play, tlay, col_gas, tau, by_band=None):
+        """by_band: optical depth per band (nbnd, nlay, ncol) -- clouds -- added where tau is stored (the _allsky entry)"""
+        if by_band is None:
+            self._c("gas_optics_lw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, tau)
+        else:
+            self._c("gas_optics_lw_direct_allsky", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, tau, by_band)
         return tau
 
-    def gas_optics_sw_direct(self, kd, play, tlay, col_gas, col_dry, tau, ssa, g):
-        self._c("gas_optics_sw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, col_dry,
-                kd.krayl, tau, ssa, g)
+    def gas_optics_sw_direct(self, kd, play, tlay, col_gas, col_dry, tau, ssa, g, by_band=None):
+        """by_band: (tau, ssa, g) per band (nbnd, nlay, ncol) -- clouds, aerosols -- combined with the gas optics where it is stored"""
+        if by_band is None:
+            self._c("gas_optics_sw_direct", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, col_dry,
+                    kd.krayl, tau, ssa, g)
+        else:
+            self._c("gas_optics_sw_direct_allsky", *self._minor_args(kd, play), *self._direct_args(kd), play, tlay, col_gas, col_dry,
+                    kd.krayl, tau, ssa, g, *by_band)
 
     def planck_source_direct(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, out=None):
         nlay, ncol = tlay.shape
@@ -236,16 +245,17 @@ class HipKernels:
                 out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"])
         return out
 
-    def gas_optics_lw_fractions(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, tau, out=None):
-        """tau and the Planck-lite outputs in one pass (rrx_gas_optics_lw_fractions)"""
+    def gas_optics_lw_fractions(self, kd, play, tlay, tlev, tsfc, sfc_lay, col_gas, tau, out=None, by_band=None):
+        """tau and the Planck-lite outputs in one pass (rrx_gas_optics_lw_fractions); by_band as in gas_optics_lw_direct"""
         nlay, ncol = tlay.shape
         if out is None:
             out = dict(pfrac=self.empty((kd.ngpt, nlay, ncol)), blay=self.empty((kd.nbnd, nlay, ncol)),
                        blev=self.empty((kd.nbnd, nlay+1, ncol)), sfc_src=self.empty((kd.ngpt, ncol)), sfc_src_jac=self.empty((kd.ngpt, ncol)))
         a = self._minor_args(kd, play)
-        self._c("gas_optics_lw_fractions", *a[:9], kd.nPlanckTemp, *a[9:16], kd.gpoint_bands, *a[16:], *self._direct_args(kd),
-                play, tlay, tlev, tsfc, sfc_lay, col_gas, kd.planck_frac, float(kd.totplnk_delta), kd.totplnk,
-                tau, out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"])
+        extra = () if by_band is None else (by_band,)
+        self._c("gas_optics_lw_fractions" + ("" if by_band is None else "_allsky"), *a[:9], kd.nPlanckTemp, *a[9:16], kd.gpoint_bands, *a[16:],
+                *self._direct_args(kd), play, tlay, tlev, tsfc, sfc_lay, col_gas, kd.planck_frac, float(kd.totplnk_delta), kd.totplnk,
+                tau, out["pfrac"], out["blay"], out["blev"], out["sfc_src"], out["sfc_src_jac"], *extra)
         return out
 
     def planck_sources_from_fractions(self, kd, fr, lay_src=None, lev_src=None):

@@ -63,7 +63,8 @@ def _use_direct(be, direct):
     return hasattr(be, "gas_optics_lw_direct") if direct is None else bool(direct)
 
 
-def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False, direct=None, lite=None):
+def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_broadband=False, keep=False, direct=None, lite=None,
+             fuse_clouds=True):
     """lite (default: broadband mode with one angle on a backend that has it): Planck fractions + band Planck functions, the
     sources are formed inside the broadband solver (the "Planck-lite" chain); keep=True materialises them for the caller."""
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
@@ -73,15 +74,18 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
     col_dry, col_gas, it = gas_state(be, kd, atm, col_dry, interpolate=not direct)
 
     fr = None
+    # all-sky on the direct path: the by-band cloud optical depth is added where tau is stored (one pass less over the g-point array)
+    tau_cld = be.cloud_optics_1scl(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei) if cloud_lut is not None else None
+    fused = tau_cld if (direct and fuse_clouds) else None
     if direct:          # product default: interpolation recomputed inside the two consumers, no intermediate arrays
         if lite:        # tau and the Planck-lite outputs in one pass over the cells
             tau = be.empty((ngpt, nlay, ncol))
-            fr = be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, tau)
+            fr = be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, tau, by_band=fused)
             src = dict(sfc_src=fr["sfc_src"], sfc_src_jac=fr["sfc_src_jac"], lay_src=None, lev_src=None)
             if keep:
                 src["lay_src"], src["lev_src"] = be.planck_sources_from_fractions(kd, fr)
         else:
-            tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)))
+            tau = be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, be.empty((ngpt, nlay, ncol)), by_band=fused)
             src = be.planck_source_direct(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas)
     else:
         if hasattr(be, "compute_tau_absorption_set"):
@@ -91,8 +95,7 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
             be.compute_tau_absorption(kd, it, atm.p_lay, atm.t_lay, col_gas, tau)
         src = be.compute_planck_source(kd, it, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm))
 
-    if cloud_lut is not None:
-        tau_cld = be.cloud_optics_1scl(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
+    if tau_cld is not None and fused is None:
         be.inc_1scalar_by_1scalar_bybnd(tau, tau_cld, kd.band_lims_gpt)
 
     sfc_emis_gpt = be.expand_and_transpose(kd.band_lims_gpt, atm.emis_sfc, ngpt)
@@ -119,7 +122,7 @@ def solve_lw(be, kd, atm, col_dry=None, cloud_lut=None, n_gauss_angles=1, do_bro
 
 
 def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_broadband=False, fused_gas=None, keep=False, direct=None,
-             aerosol_lut=None, delta_aerosol=False):
+             aerosol_lut=None, delta_aerosol=False, fuse_clouds=True):
     ncol, nlay, ngpt = atm.ncol, atm.nlay, kd.ngpt
     if fused_gas is None:
         fused_gas = hasattr(be, "gas_optics_sw_fused")
@@ -129,11 +132,17 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
     # clear sky: the asymmetry parameter of the gas optics is identically zero; the HIP entry points take "no g array"
     # natively (nothing written by the gas optics, nothing read by the solver)
     g_zero = bool(fused_gas and cloud_lut is None and aerosol_lut is None and getattr(be, "supports_null_g", False))
+    cld = None
+    if cloud_lut is not None:
+        cld = be.cloud_optics_2str(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
+        if delta_cloud:
+            be.delta_scale_2str_k(*cld)
+    fused = cld if (direct and fuse_clouds) else None          # added where the gas optics is stored
     if fused_gas:
         tau = be.empty((ngpt, nlay, ncol)); ssa = be.empty((ngpt, nlay, ncol))
         g = None if g_zero else be.empty((ngpt, nlay, ncol))
         if direct:
-            be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
+            be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g, by_band=fused)
         else:
             be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, tau, ssa, g)
     else:
@@ -145,11 +154,8 @@ def solve_sw(be, kd, atm, col_dry=None, cloud_lut=None, delta_cloud=False, do_br
     toa_src = be.spread_col(ncol, kd.solar_source)
     be.scaling_to_subset(toa_src, atm.tsi_scaling)
 
-    if cloud_lut is not None:
-        tc, wc, gc = be.cloud_optics_2str(cloud_lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
-        if delta_cloud:
-            be.delta_scale_2str_k(tc, wc, gc)
-        be.inc_2stream_by_2stream_bybnd(tau, ssa, g, tc, wc, gc, kd.band_lims_gpt)
+    if cld is not None and fused is None:
+        be.inc_2stream_by_2stream_bybnd(tau, ssa, g, *cld, kd.band_lims_gpt)
 
     if aerosol_lut is not None:
         # /root/reference/src_test/Radiation_solver.cu:794-809
@@ -184,7 +190,7 @@ class ResidentSolver:
 
     STAGES = ("lw_gas_optics", "lw_planck", "lw_solver", "lw_reduce", "sw_gas_optics", "sw_solver", "sw_reduce")
 
-    def __init__(self, be, kd_lw, kd_sw, atm, do_broadband=False, overlap=False):
+    def __init__(self, be, kd_lw, kd_sw, atm, do_broadband=False, overlap=False, cloud_luts=None):
         import torch
         self.torch = torch
         # overlap: LW and SW chains are independent, so they can run on two HIP streams and share the chip (the gather-
@@ -193,7 +199,10 @@ class ResidentSolver:
         self.streams = [torch.cuda.Stream(device=be.device), torch.cuda.Stream(device=be.device)] if overlap else None
         self.be, self.kd_lw, self.kd_sw, self.atm = be, kd_lw, kd_sw, atm
         self.do_broadband = do_broadband
-        self.g_zero = bool(int(os.environ.get("RRX_G_ZERO", "1")))     # clear sky: g == 0 is neither written nor read
+        # all-sky (BASELINE C5): (lw_lut, sw_lut) of cloud optics; clouds are added by band after the gas optics, delta-scaled in SW
+        self.cloud_luts = cloud_luts
+        self.fuse_clouds = bool(int(os.environ.get("RRX_FUSE_CLOUDS", "1")))
+        self.g_zero = cloud_luts is None and bool(int(os.environ.get("RRX_G_ZERO", "1")))     # clear sky: g == 0 is neither written nor read
         self.direct = bool(int(os.environ.get("RRX_DIRECT", "1")))     # interpolation state recomputed inside its consumers
         # broadband mode: Planck fractions + band Planck functions, sources formed inside the LW solver ("Planck-lite" chain)
         self.lite = self.direct and do_broadband and bool(int(os.environ.get("RRX_LITE", "1")))
@@ -260,13 +269,22 @@ class ResidentSolver:
             be._c("get_col_dry", ncol, nlay, atm.vmr["h2o"], atm.p_lev, col_dry)
             col_gas = be.fill_gases(kd, atm.vmr, col_dry)
             it = None if self.direct else be.interpolation(kd, atm.p_lay, atm.t_lay, col_gas)
+            # all-sky: the by-band cloud properties are computed first and added where the gas optics is stored (fused); with
+            # RRX_FUSE_CLOUDS=0 by the reference's separate increment kernels afterwards
+            fuse = self.cloud_luts is not None and self.direct and self.fuse_clouds
             if kind == "lw":
+                tc = None
+                if self.cloud_luts is not None:     # /root/reference/src_test/Radiation_solver.cu:497-512
+                    tc = be.cloud_optics_1scl(self.cloud_luts[0], atm.lwp, atm.iwp, atm.rel, atm.dei)
                 if self.lite:
-                    be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, buf["tau"], out=buf)
+                    be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, _sfc_lay(atm), col_gas, buf["tau"], out=buf,
+                                               by_band=tc if fuse else None)
                 elif self.direct:
-                    be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                    be.gas_optics_lw_direct(kd, atm.p_lay, atm.t_lay, col_gas, buf["tau"], by_band=tc if fuse else None)
                 else:
                     be.compute_tau_absorption_set(kd, it, atm.p_lay, atm.t_lay, col_gas, buf["tau"])
+                if tc is not None and not fuse:
+                    be.inc_1scalar_by_1scalar_bybnd(buf["tau"], tc, kd.band_lims_gpt)
                 mark("lw_gas_optics", True)
                 mark("lw_planck")
                 srcs = None if self.lite else dict(sfc_src=buf["sfc_src"], lay_src=buf["lay_src"], lev_src=buf["lev_src"], sfc_src_jac=buf["sfc_src_jac"])
@@ -299,12 +317,18 @@ class ResidentSolver:
             else:
                 # clear sky: the asymmetry parameter is identically zero; the fused broadband solver takes "no g" natively
                 gbuf = None if (self.g_zero and self.do_broadband) else buf["g"]
+                cld = None
+                if self.cloud_luts is not None:     # Radiation_solver.cu:773-792
+                    cld = be.cloud_optics_2str(self.cloud_luts[1], atm.lwp, atm.iwp, atm.rel, atm.dei)
+                    be.delta_scale_2str_k(*cld)
                 if self.direct:
-                    be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
+                    be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf, by_band=cld if fuse else None)
                 else:
                     be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
                 toa = be.spread_col(ncol, kd.solar_source)
                 be.scaling_to_subset(toa, atm.tsi_scaling)
+                if cld is not None and not fuse:
+                    be.inc_2stream_by_2stream_bybnd(buf["tau"], buf["ssa"], gbuf, *cld, kd.band_lims_gpt)
                 mark("sw_gas_optics", True)
                 mark("sw_solver")
                 be._c("expand_and_transpose", ncol, kd.nbnd, kd.band_lims_gpt, atm.sfc_alb_dir, self.alb_dir)

@@ -729,3 +729,29 @@ def test_bench_line_keeps_its_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["parity_max_rel"] <= 1e-6
     assert abs(sum(s["ms"] for s in d["stages"].values()) - d["ms_per_step"]) / d["ms_per_step"] < 0.05   # the stages account for the step
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_cloud_increments_fused_into_gas_optics(dt, top_at_1, hip_f64, hip_f32):
+    """All-sky on the product chain: the by-band cloud properties are combined with the gas optics where the g-point arrays are
+    stored (rrx_gas_optics_{lw_direct,lw_fractions,sw_direct}_allsky) instead of by increment_*_bybnd afterwards. Same
+    arithmetic, so the same bits -- tau, ssa, g and the fluxes -- on the real spectral shape, windowed kernel and hand-backs."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    nb = 16
+    kl = be.upload_kdist(synthetic.make_kdist("lw", ngpt=256, nbnd=nb).astype(be.np_dtype))
+    ks = be.upload_kdist(synthetic.make_kdist("sw", ngpt=256, nbnd=nb).astype(be.np_dtype))
+    atm = pipeline.upload_atmosphere(be, synthetic.make_atmosphere(200, 140, nbnd_lw=nb, nbnd_sw=nb, clouds=True, top_at_1=top_at_1, seed=31).astype(be.np_dtype))
+    cast = lambda lut: be.upload_lut({k: (v.astype(be.np_dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
+    ll, ls = cast(synthetic.make_cloud_lut(nb, "lw")), cast(synthetic.make_cloud_lut(nb, "sw"))
+    N = be.to_numpy
+    for lite in (True, False):
+        a = pipeline.solve_lw(be, kl, atm, cloud_lut=ll, do_broadband=True, lite=lite, keep=True, fuse_clouds=True)
+        b = pipeline.solve_lw(be, kl, atm, cloud_lut=ll, do_broadband=True, lite=lite, keep=True, fuse_clouds=False)
+        for k in ("tau", "flux_up", "flux_dn"):
+            assert np.array_equal(N(a[k]), N(b[k])), (lite, k)
+    a = pipeline.solve_sw(be, ks, atm, cloud_lut=ls, delta_cloud=True, do_broadband=True, keep=True, fuse_clouds=True)
+    b = pipeline.solve_sw(be, ks, atm, cloud_lut=ls, delta_cloud=True, do_broadband=True, keep=True, fuse_clouds=False)
+    for k in ("tau", "ssa", "g", "flux_up", "flux_dn", "flux_dn_dir"):
+        assert np.array_equal(N(a[k]), N(b[k])), k
+    assert float(N(a["g"]).max()) > 0.2          # clouds are there
