@@ -117,7 +117,16 @@ class Gas_optics_rrtmgp_gpu : public Gas_optics_gpu
                 std::unique_ptr<Optical_props_arry_gpu>& optical_props,
                 Source_func_lw_gpu& sources,
                 const Array_gpu<Float,2>& col_dry,
-                const Array_gpu<Float,2>& tlev);
+                const Array_gpu<Float,2>& tlev)
+        { gas_optics(play, plev, tlay, tsfc, gas_desc, optical_props, sources, col_dry, tlev, nullptr); }
+        // Addition: optical properties given by band (clouds) that are added to the gas optics where it is stored --
+        // add_to(optical_props, *add_by_band) folded into the call, same bits, without a second pass over the g-point arrays
+        void gas_optics(
+                const Array_gpu<Float,2>& play, const Array_gpu<Float,2>& plev, const Array_gpu<Float,2>& tlay,
+                const Array_gpu<Float,1>& tsfc, const Gas_concs_gpu& gas_desc,
+                std::unique_ptr<Optical_props_arry_gpu>& optical_props, Source_func_lw_gpu& sources,
+                const Array_gpu<Float,2>& col_dry, const Array_gpu<Float,2>& tlev,
+                const Optical_props_1scl_gpu* add_by_band);
 
         // shortwave variant
         void gas_optics(
@@ -127,7 +136,13 @@ class Gas_optics_rrtmgp_gpu : public Gas_optics_gpu
                 const Gas_concs_gpu& gas_desc,
                 std::unique_ptr<Optical_props_arry_gpu>& optical_props,
                 Array_gpu<Float,2>& toa_src,
-                const Array_gpu<Float,2>& col_dry);
+                const Array_gpu<Float,2>& col_dry)
+        { gas_optics(play, plev, tlay, gas_desc, optical_props, toa_src, col_dry, nullptr); }
+        void gas_optics(
+                const Array_gpu<Float,2>& play, const Array_gpu<Float,2>& plev, const Array_gpu<Float,2>& tlay,
+                const Gas_concs_gpu& gas_desc, std::unique_ptr<Optical_props_arry_gpu>& optical_props,
+                Array_gpu<Float,2>& toa_src, const Array_gpu<Float,2>& col_dry,
+                const Optical_props_2str_gpu* add_by_band);
 
         // Extras for tests / diagnostics: the reduced gas list and host copies of the index tables.
         const Array<std::string,1>& get_gas_names() const { return gas_names; }

@@ -88,6 +88,7 @@ class Optical_props_2str_gpu : public Optical_props_arry_gpu
         const Array_gpu<Float,3>& get_g  () const { materialize_g(); return g; }
         void delta_scale(const Array_gpu<Float,3>& forward_frac=Array_gpu<Float,3>());
         void set_g_zero() { g_zero = true; }
+        void forget_g_zero() { g_zero = false; }      // the array behind g is about to be written in full
         const Float* get_g_or_null() const { return g_zero ? nullptr : g.ptr(); }
     private:
         void materialize_g() const;

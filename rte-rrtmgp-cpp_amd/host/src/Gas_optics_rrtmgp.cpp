@@ -442,9 +442,13 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
         std::unique_ptr<Optical_props_arry_gpu>& optical_props,
         Source_func_lw_gpu& sources,
         const Array_gpu<Float,2>& col_dry,
-        const Array_gpu<Float,2>& tlev)
+        const Array_gpu<Float,2>& tlev,
+        const Optical_props_1scl_gpu* add_by_band)
 {
     (void)plev;
+    if (add_by_band != nullptr && add_by_band->get_ngpt() != this->get_nband())
+        throw std::runtime_error("Cannot add optical properties with incompatible band - gpoint combination");
+    const Float* by_band_tau = add_by_band ? add_by_band->get_tau().ptr() : nullptr;
     const int ncol = play.dim(1);
     const int nlay = play.dim(2);
     const int ngas = this->gas_names.dim(1);
@@ -457,7 +461,7 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
     if (sources.planck_lite_wanted())
     {
         // optical depths + Planck fractions + band Planck functions in one pass; the broadband solver forms the sources
-        RRX_CALL(rrx_gas_optics_lw_fractions,
+        RRX_CALL(rrx_gas_optics_lw_fractions_allsky,
                 ncol, nlay, this->get_nband(), this->get_ngpt(), ngas, this->get_nflav(), neta, npres, ntemp, this->get_nPlanckTemp(),
                 nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o,
                 gpoint_flavor_gpu.ptr(), this->get_band_lims_gpoint_gpu().ptr(), this->get_gpoint_bands_gpu().ptr(),
@@ -470,11 +474,11 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
                 play.ptr(), tlay.ptr(), tlev.ptr(), tsfc.ptr(), sfc_lay, col_gas.ptr(),
                 planck_frac_gpu.ptr(), totplnk_delta, totplnk_gpu.ptr(),
                 optical_props->get_tau().ptr(), sources.get_planck_frac().ptr(), sources.get_planck_lay().ptr(), sources.get_planck_lev().ptr(),
-                sources.get_sfc_source().ptr(), sources.get_sfc_source_jac().ptr());
+                sources.get_sfc_source().ptr(), sources.get_sfc_source_jac().ptr(), by_band_tau);
         sources.set_fractions_valid(true);
         return;
     }
-    RRX_CALL(rrx_gas_optics_lw_direct, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), optical_props->get_tau().ptr());
+    RRX_CALL(rrx_gas_optics_lw_direct_allsky, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), optical_props->get_tau().ptr(), by_band_tau);
     sources.ensure_full_arrays();
     sources.set_fractions_valid(false);
     RRX_CALL(rrx_planck_source_direct,
@@ -494,18 +498,33 @@ void Gas_optics_rrtmgp_gpu::gas_optics(
         const Gas_concs_gpu& gas_desc,
         std::unique_ptr<Optical_props_arry_gpu>& optical_props,
         Array_gpu<Float,2>& toa_src,
-        const Array_gpu<Float,2>& col_dry)
+        const Array_gpu<Float,2>& col_dry,
+        const Optical_props_2str_gpu* add_by_band)
 {
     (void)plev;
+    if (add_by_band != nullptr && add_by_band->get_ngpt() != this->get_nband())
+        throw std::runtime_error("Cannot add optical properties with incompatible band - gpoint combination");
     const int ncol = play.dim(1);
     const int nlay = play.dim(2);
     const int ngas = this->gas_names.dim(1);
     Array_gpu<Float,3> col_gas;
     fill_col_gas(ncol, nlay, gas_desc, col_dry, col_gas);
     // absorption + Rayleigh + combine in one pass over the output (same arithmetic as the three reference launchers)
-    RRX_CALL(rrx_gas_optics_sw_direct, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), col_dry.ptr(), krayl_gpu.ptr(),
-            optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), static_cast<Float*>(nullptr));
-    optical_props->set_g_zero();          // g == 0: not written; materialised on the first get_g() (clouds, output)
+    if (add_by_band != nullptr)
+    {
+        // all-sky: gas + by-band properties combined where they are stored; g is a real array from here on
+        Optical_props_2str_gpu& op = dynamic_cast<Optical_props_2str_gpu&>(*optical_props);
+        op.forget_g_zero();
+        RRX_CALL(rrx_gas_optics_sw_direct_allsky, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), col_dry.ptr(), krayl_gpu.ptr(),
+                op.get_tau().ptr(), op.get_ssa().ptr(), op.get_g().ptr(),
+                add_by_band->get_tau().ptr(), add_by_band->get_ssa().ptr(), add_by_band->get_g().ptr());
+    }
+    else
+    {
+        RRX_CALL(rrx_gas_optics_sw_direct, RRX_MINOR_ARGS, RRX_INTERP_ARGS, play.ptr(), tlay.ptr(), col_gas.ptr(), col_dry.ptr(), krayl_gpu.ptr(),
+                optical_props->get_tau().ptr(), optical_props->get_ssa().ptr(), static_cast<Float*>(nullptr));
+        optical_props->set_g_zero();          // g == 0: not written; materialised on the first get_g() (clouds, output)
+    }
     // External source function is constant in the column.
     RRX_CALL(rrx_spread_col, ncol, this->get_ngpt(), toa_src.ptr(), solar_source_gpu.ptr());
 }

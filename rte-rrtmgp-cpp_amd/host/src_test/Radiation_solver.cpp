@@ -263,13 +263,12 @@ void Radiation_solver_longwave::solve_gpu(
         else
             col_dry_s = sub2(col_dry, n_lay);
 
-        kdist_gpu->gas_optics(p_lay_s, p_lev_s, t_lay_s, t_sfc_s, gas_concs_subset, ws.optical_props, *ws.sources, col_dry_s, t_lev_s);
-
+        // (cloud optics first: its by-band optical depth is added inside gas_optics where tau is stored -- the add_to() of
+        //  Radiation_solver.cu:508-511 folded into the producer)
         if (switch_cloud_optics)
-        {
             cloud_optics_gpu->cloud_optics(sub2(lwp, n_lay), sub2(iwp, n_lay), sub2(rel, n_lay), sub2(dei, n_lay), *ws.cloud_optical_props);
-            add_to(dynamic_cast<Optical_props_1scl_gpu&>(*ws.optical_props), *ws.cloud_optical_props);
-        }
+        kdist_gpu->gas_optics(p_lay_s, p_lev_s, t_lay_s, t_sfc_s, gas_concs_subset, ws.optical_props, *ws.sources, col_dry_s, t_lev_s,
+                              switch_cloud_optics ? ws.cloud_optical_props.get() : nullptr);
 
         if (switch_output_optical)
         {
@@ -407,18 +406,19 @@ void Radiation_solver_shortwave::solve_gpu(
         else
             col_dry_s = sub2(col_dry, n_lay);
 
-        Array_gpu<Float,2> toa_src_s({n_in, n_gpt});
-        kdist_gpu->gas_optics(p_lay_s, p_lev_s, t_lay_s, gas_concs_subset, ws.optical_props, toa_src_s, col_dry_s);
-        Array_gpu<Float,1> tsi_s = sub1(tsi_scaling);
-        RRX_CALL(rrx_scaling_to_subset, n_in, n_gpt, toa_src_s.ptr(), tsi_s.ptr());
-
+        // (cloud optics first: gas and cloud properties are combined inside gas_optics where the g-point arrays are stored --
+        //  the add_to() of Radiation_solver.cu:788-791 folded into the producer)
         if (switch_cloud_optics)
         {
             cloud_optics_gpu->cloud_optics(sub2(lwp, n_lay), sub2(iwp, n_lay), sub2(rel, n_lay), sub2(dei, n_lay), *ws.cloud_optical_props);
             if (switch_delta_cloud)
                 ws.cloud_optical_props->delta_scale();
-            add_to(dynamic_cast<Optical_props_2str_gpu&>(*ws.optical_props), *ws.cloud_optical_props);
         }
+        Array_gpu<Float,2> toa_src_s({n_in, n_gpt});
+        kdist_gpu->gas_optics(p_lay_s, p_lev_s, t_lay_s, gas_concs_subset, ws.optical_props, toa_src_s, col_dry_s,
+                              switch_cloud_optics ? ws.cloud_optical_props.get() : nullptr);
+        Array_gpu<Float,1> tsi_s = sub1(tsi_scaling);
+        RRX_CALL(rrx_scaling_to_subset, n_in, n_gpt, toa_src_s.ptr(), tsi_s.ptr());
 
         if (switch_aerosol_optics)
         {
