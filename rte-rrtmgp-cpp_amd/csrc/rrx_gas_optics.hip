@@ -463,7 +463,8 @@ tau_absorption_kernel(
     constexpr int G = (sizeof(F) == 8 && MODE == 1) ? 2 : 4;
     constexpr int NPRE = (sizeof(F) == 8) ? ((MODE == 1) ? 0 : 2) : 1;
 #endif
-    [[maybe_unused]] int cb = 0;                 // CLD: band (0-based) of the g-point being stored; g-points ascend within a pass
+    [[maybe_unused]] int cb = 0, cb_have = -1;   // CLD: band (0-based) of the g-point being stored; g-points ascend within a pass
+    [[maybe_unused]] F c_tau = F(0.), c_ssa = F(0.), c_g = F(0.);
     auto gpoint_group = [&](const int ig0, const int gend, const int c, const int n, const Slots& sl, const F (&sc)[SL])
     {
         int igs[G];
@@ -634,7 +635,8 @@ tau_absorption_kernel(
                     if constexpr (CLD)
                     {
                         while (ig0 + u + 1 > ia.cld_lims[2*cb+1]) ++cb;
-                        stream_store(tau + o, t[u] + ia.cld_tau[idx + size_t(cb)*ncl]);
+                        if (cb != cb_have) { cb_have = cb; c_tau = ia.cld_tau[idx + size_t(cb)*ncl]; }
+                        stream_store(tau + o, t[u] + c_tau);
                     }
                     else stream_store(tau + o, t[u]);
                 }
@@ -646,9 +648,14 @@ tau_absorption_kernel(
                     if constexpr (CLD)
                     {
                         while (ig0 + u + 1 > ia.cld_lims[2*cb+1]) ++cb;
-                        const size_t b = idx + size_t(cb)*ncl;
+                        if (cb != cb_have)
+                        {
+                            cb_have = cb;
+                            const size_t b = idx + size_t(cb)*ncl;
+                            c_tau = ia.cld_tau[b]; c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b];
+                        }
                         F gg = F(0.);
-                        add_by_band_2str(tt, ww, gg, ia.cld_tau[b], ia.cld_ssa[b], ia.cld_g[b]);
+                        add_by_band_2str(tt, ww, gg, c_tau, c_ssa, c_g);
                         stream_store(tau + o, tt); stream_store(ssa + o, ww); stream_store(g + o, gg);
                     }
                     else
@@ -1398,7 +1405,8 @@ gas_window_kernel(
     }
 
     int cur_flav = -1, je_lo = 1;
-    [[maybe_unused]] int cb = 0;                 // CLD: band (0-based) of the g-point being stored (g-points ascend over the chunk loop)
+    [[maybe_unused]] int cb = 0, cb_have = -1;   // CLD: band (0-based) of the g-point being stored (g-points ascend over the chunk loop)
+    [[maybe_unused]] F c_tau = F(0.), c_ssa = F(0.), c_g = F(0.);
     F fm[8], cm[2], fn[4]; int je[2] = {1, 1};
     #pragma unroll
     for (int i=0; i<8; ++i) fm[i] = F(0.);
@@ -1613,10 +1621,21 @@ gas_window_kernel(
             {
                 const int gi = gi0 + u, ig = c0 + gi;
                 const size_t o = idx + size_t(ig)*ncl;
-                if constexpr (CLD) { while (ig + 1 > ia.cld_lims[2*cb+1]) ++cb; }
+                if constexpr (CLD)
+                {
+                    // the cell's by-band values are read once per band (16 g-points), not per g-point
+                    while (ig + 1 > ia.cld_lims[2*cb+1]) ++cb;
+                    if (PF || cb != cb_have)        // (the fractions form has no register to keep the value in: re-read, an L1 hit)
+                    {
+                        cb_have = cb;
+                        const size_t b = idx + size_t(cb)*ncl;
+                        c_tau = ia.cld_tau[b];
+                        if constexpr (MODE != 2) { c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b]; }
+                    }
+                }
                 if constexpr (MODE == 2)
                 {
-                    if constexpr (CLD) { if (active) stream_store(tau + o, t[u] + ia.cld_tau[idx + size_t(cb)*ncl]); }
+                    if constexpr (CLD) { if (active) stream_store(tau + o, t[u] + c_tau); }
                     else if (active) stream_store(tau + o, t[u]);
                 }
                 else
@@ -1625,9 +1644,8 @@ gas_window_kernel(
                     F ww = (tt > F(2.)*Lim<F>::eps()) ? ray[u] / tt : F(0.);
                     if constexpr (CLD)
                     {
-                        const size_t b = idx + size_t(cb)*ncl;
                         F gg = F(0.);
-                        add_by_band_2str(tt, ww, gg, ia.cld_tau[b], ia.cld_ssa[b], ia.cld_g[b]);
+                        add_by_band_2str(tt, ww, gg, c_tau, c_ssa, c_g);
                         if (active) { stream_store(tau + o, tt); stream_store(ssa + o, ww); stream_store(g + o, gg); }
                     }
                     else if (active)
