@@ -473,9 +473,11 @@ lw_noscat_bb_kernel(
             const F pa = (j == 0) ? cur.x_prev.v[v] : cur.a1[max(j-1, 0)].v[v];
             const F pb = (j == K) ? cur.x_next.v[v] : cur.a1[min(j, K-1)].v[v];
             const F bvv = lds_b[(K+j)*V+v][tid];
-            if (t <= 0) return pb * bvv;
-            if (t >= nlay) return pa * bvv;
-            return sqrt_pos(pa*pb) * bvv;
+            // selects, not branches: the first and the last level take the fraction of their one layer (every lane evaluates the
+            // square root anyway; two divergent branches per level cost more scalar instructions than the selects)
+            const F mid = sqrt_pos(pa*pb);
+            const F f = (t <= 0) ? pb : ((t >= nlay) ? pa : mid);
+            return f * bvv;
         }
     };
 
