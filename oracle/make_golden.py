@@ -13,6 +13,7 @@ element-wise optical-props kernels.
 """
 import hashlib
 import os
+import subprocess
 import sys
 import numpy as np
 
@@ -168,8 +169,91 @@ def glue_case(dtype, top_at_1, seed):
     return out
 
 
+def tall_solver_case(top_at_1, nlay, seed, ncol=17, ngpt=3):
+    """random-input LW / SW solver runs of the reference kernel text at the layer counts the production
+    tilings serve (60 and 140 layers), 17 columns (16 column-lanes + 1). The inputs are regenerated from the seed by the tests
+    (tests/cases.py:tall_inputs, digest stored); the fixture holds the reference outputs. The g = 0 run (the clear-sky form of
+    the fused SW kernel) is stored as broadband sums."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import cases
+    ref = O.CpuKernels("ref", np.float64)
+    I = cases.tall_inputs(seed, ncol, nlay, ngpt)
+    sec = ref.lw_secants_array(ncol, ngpt, 1, 4, ref.asarray(pipeline.GAUSS_DS))
+    fl = ref.lw_solver_noscat(top_at_1, sec, ref.asarray(np.array([1.0])), I["tau"], I["lay"], I["lev"], I["emis"], I["ssrc"])
+    fs = ref.sw_solver_2stream(top_at_1, I["tau"], I["ssa"], I["g"], I["mu0"], I["adir"], I["adif"], I["inc"])
+    f0 = ref.sw_solver_2stream(top_at_1, I["tau"], I["ssa"], np.zeros_like(I["g"]), I["mu0"], I["adir"], I["adif"], I["inc"])
+    return dict(inputs_digest=np.array(cases.arrays_digest(I)),
+                lw_flux_up=fl["flux_up"], lw_flux_dn=fl["flux_dn"],
+                sw_flux_up=fs["flux_up"], sw_flux_dn=fs["flux_dn"], sw_flux_dir=fs["flux_dir"],
+                sw_g0_bb_up=ref.sum_broadband(f0["flux_up"]), sw_g0_bb_dn=ref.sum_broadband(f0["flux_dn"]),
+                sw_g0_bb_dir=ref.sum_broadband(f0["flux_dir"]),
+                meta=np.array([ncol, nlay, int(top_at_1), seed, ngpt]))
+
+
+def slim_chain(case):
+    """Atmosphere in, broadband fluxes out: what a whole-chain replay needs (the product chain keeps no intermediates)."""
+    keep = ("p_lay", "p_lev", "t_lay", "t_lev", "t_sfc", "col_dry", "mu0", "meta", "lw_kdist_digest", "sw_kdist_digest",
+            "lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dir", "sw_toa_src",
+            "lw_sfc_emis_gpt", "sw_alb_dir", "sw_alb_dif")
+    return {k: v for k, v in case.items() if k in keep or k.startswith("vmr_")}
+
+
+def optics_lut_digest(lut):
+    h = hashlib.sha256()
+    for k in sorted(lut):
+        h.update(k.encode()); h.update(np.ascontiguousarray(np.asarray(lut[k], dtype=np.float64)).tobytes())
+    return h.hexdigest()
+
+
+def cloud_case(dtype, kind, seed):
+    """The reference's own CPU class Cloud_optics (src/Cloud_optics.cpp:29-232, compiled unmodified: oracle/refcpu_runner.cpp)
+    on a synthetic LUT: both cloud_optics() overloads, particle sizes over the whole table incl. both end points, cloud-free
+    cells, cells with only liquid / only ice."""
+    import refcpu_py
+    rng = np.random.default_rng(seed)
+    nbnd, nlay, ncol = 6, 9, 11
+    lut = synthetic.make_cloud_lut(nbnd, kind)
+    shp = (nlay, ncol)
+    lwp = np.where(rng.uniform(size=shp) < 0.35, 0., rng.uniform(0., 60., shp))
+    iwp = np.where(rng.uniform(size=shp) < 0.35, 0., rng.uniform(0., 40., shp))
+    rel = rng.uniform(lut["radliq_lwr"], lut["radliq_upr"], shp); dei = rng.uniform(lut["diamice_lwr"], lut["diamice_upr"], shp)
+    rel[0, 0], rel[0, 1] = lut["radliq_lwr"], lut["radliq_upr"]
+    dei[0, 0], dei[0, 1] = lut["diamice_lwr"], lut["diamice_upr"]
+    lwp[0, :2] = 30.; iwp[0, :2] = 20.
+    lutd = {k: (v.astype(dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()}
+    ins = [a.astype(dtype) for a in (lwp, iwp, rel, dei)]
+    t2, w2, g2, t1 = refcpu_py.cloud_optics(dtype, lutd, *ins)
+    return dict(lut_kind=np.array(kind), lut_nbnd=np.array(nbnd), lut_digest=np.array(optics_lut_digest(lut)),
+                clwp=ins[0], ciwp=ins[1], reliq=ins[2], deice=ins[3], tau_2str=t2, ssa_2str=w2, g_2str=g2, tau_1scl=t1,
+                meta=np.array([ncol, nlay, 0, seed]))
+
+
+def aerosol_case(dtype, table, seed):
+    """The reference's own CPU class Aerosol_optics (src/Aerosol_optics.cpp:24-224, compiled unmodified) on the real CAMS
+    tables of the reference tree (data/aerosol_optics.nc = tests/golden/aerosol_optics.nc) and on a synthetic table with
+    another band count. Surface-first columns (the CPU text has no abs() on dp) and rh <= 1 (its humidity-class search is
+    unbounded above the last class); two of the eleven species are given as profiles, as in the all-sky input file."""
+    import refcpu_py
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import cases
+    with tempfile.TemporaryDirectory() as d:
+        lut = cases.real_aerosol_lut(d) if table == "real" else synthetic.make_aerosol_lut(5)
+    atm = synthetic.make_atmosphere(13, 21, aerosols=True, top_at_1=False, seed=seed)
+    rh = np.minimum(atm.rh, 1.0)
+    rh[0, 0] = lut["rh_upper"][3]                       # exactly on a class boundary
+    aermr = [atm.aermr["aermr%02d" % i].astype(dtype) for i in range(1, 12)]
+    lutd = {k: v.astype(dtype) for k, v in lut.items()}
+    tau, ssa, g = refcpu_py.aerosol_optics(dtype, lutd, aermr, rh.astype(dtype), atm.p_lev.astype(dtype))
+    out = dict(table=np.array(table), lut_digest=np.array(optics_lut_digest(lut)), rh=rh.astype(dtype), p_lev=atm.p_lev.astype(dtype),
+               tau=tau, ssa=ssa, g=g, meta=np.array([13, 21, 0, seed]))
+    out.update({"aermr%02d" % (i+1): m for i, m in enumerate(aermr)})
+    return out
+
+
 def main():
     O.build(ref=True)
+    subprocess.run(["make", "-C", HERE, "refcpu"], check=True, stdout=subprocess.DEVNULL)
     os.makedirs(GOLDEN, exist_ok=True)
     total = 0
     for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
@@ -189,6 +273,26 @@ def main():
                 np.savez_compressed(path, **glue_case(dtype, top, 21 + int(top)))
                 total += os.path.getsize(path)
                 print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+    # production tilings: 60- and 140-layer solver runs and a 140-layer whole chain
+    for top in (False, True):
+        for nlay in (60, 140):
+            path = os.path.join(GOLDEN, f"tall_f64_top{int(top)}_nlay{nlay}.npz")
+            np.savez_compressed(path, **tall_solver_case(top, nlay, 50 + nlay + int(top)))
+            total += os.path.getsize(path)
+            print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+        path = os.path.join(GOLDEN, f"chainbb_f64_top{int(top)}_17x140.npz")
+        np.savez_compressed(path, **slim_chain(chained_case(np.float64, top, 17, 140)))
+        total += os.path.getsize(path)
+        print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+    # the reference's CPU classes for cloud / aerosol optics
+    for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        cases_ = [(f"cloud_{tag}_lw", cloud_case(dtype, "lw", 31)), (f"cloud_{tag}_sw", cloud_case(dtype, "sw", 32)),
+                  (f"aerosol_{tag}_real", aerosol_case(dtype, "real", 41)), (f"aerosol_{tag}_synthetic", aerosol_case(dtype, "synthetic", 42))]
+        for name, case in cases_:
+            path = os.path.join(GOLDEN, name + ".npz")
+            np.savez_compressed(path, **case)
+            total += os.path.getsize(path)
+            print(f"wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
     # degenerate shape: 1 column x 4 layers
     case = chained_case(np.float64, False, 1, 4)
     path = os.path.join(GOLDEN, "chain_f64_top0_1x4.npz")

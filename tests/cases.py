@@ -25,6 +25,29 @@ def kdist_digest(kd):
     return h.hexdigest()
 
 
+def arrays_digest(d):
+    h = hashlib.sha256()
+    for k in sorted(d):
+        h.update(k.encode()); h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()
+
+
+def tall_inputs(seed, ncol, nlay, ngpt):
+    """Seeded fp64 inputs of the tall solver fixtures (oracle/make_golden.py:tall_solver_case): the fixture stores their
+    digest and the reference outputs. PCG64 + uniform() are stable across numpy versions."""
+    rng = np.random.default_rng(seed)
+    shp = (ngpt, nlay, ncol)
+    d = dict(tau=10.0**rng.uniform(-6, 2, shp), lay=rng.uniform(5., 40., shp), lev=rng.uniform(5., 40., (ngpt, nlay+1, ncol)),
+             emis=rng.uniform(0.8, 1.0, (ngpt, ncol)), ssrc=rng.uniform(5., 40., (ngpt, ncol)),
+             ssa=rng.uniform(0., 1., shp), g=rng.uniform(-0.3, 0.9, shp), mu0=rng.uniform(0.05, 1.0, ncol),
+             adif=rng.uniform(0., 0.6, (ngpt, ncol)), inc=rng.uniform(0., 5., (ngpt, ncol)))
+    d["adir"] = np.ascontiguousarray(np.repeat(rng.uniform(0., 0.6, ncol)[None, :], ngpt, axis=0))
+    d["tau"][0, 0, :] = 0.0
+    d["ssa"][1, ::7, :] = 1.0
+    d["ssa"][2, ::5, :] = 0.0
+    return d
+
+
 def rel_err(a, b, floor=1e-6):
     """max |a-b| / (|b| + floor*max|b|): relative error that does not blow up at the zeros of b.
     fp32 comparisons use floor = 1e-2: single-precision cancellation in the source terms leaves an ABSOLUTE error of
@@ -186,6 +209,100 @@ def run_random_case(be, G, tol):
     t1, w1, g1 = up(G["lw_tau"].copy()), up(G["sw_ssa"].copy()), up(G["sw_g"].copy())
     be.delta_scale_2str_k(t1, w1, g1)
     ck.close("op_ds_tau", t1, G["op_ds_tau"]); ck.close("op_ds_ssa", w1, G["op_ds_ssa"]); ck.close("op_ds_g", g1, G["op_ds_g"])
+    return ck.worst
+
+
+def run_tall_case(be, G, tol):
+    """60- / 140-layer random-input solver runs against the reference kernel text: the per-g-point kernels and, on backends
+    with a broadband mode, the fused forms against the in-order g-point sums of the same fixture."""
+    ck = Checker(be, tol)
+    ncol, nlay, top_at_1, seed, ngpt = [int(x) for x in G["meta"]]
+    I = tall_inputs(seed, ncol, nlay, ngpt)
+    assert arrays_digest(I) == str(G["inputs_digest"]), "seeded inputs drifted: regenerate goldens"
+    up = be.asarray
+    sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+    lw = (bool(top_at_1), sec, w, up(I["tau"]), up(I["lay"]), up(I["lev"]), up(I["emis"]), up(I["ssrc"]))
+    fl = be.lw_solver_noscat(*lw)
+    ck.close("lw_flux_up", fl["flux_up"], G["lw_flux_up"]); ck.close("lw_flux_dn", fl["flux_dn"], G["lw_flux_dn"])
+    sw = (bool(top_at_1), up(I["tau"]), up(I["ssa"]), up(I["g"]), up(I["mu0"]), up(I["adir"]), up(I["adif"]), up(I["inc"]))
+    fs = be.sw_solver_2stream(*sw)
+    for k in ("up", "dn", "dir"):
+        ck.close("sw_flux_" + k, fs["flux_" + k], G["sw_flux_" + k])
+    if be.name != "ref":
+        seqsum = lambda a: np.add.reduce(a, axis=0)          # ascending g-point order = sum_broadband's
+        bb = be.lw_solver_noscat(*lw, do_broadband=True)
+        ck.close("lw_bb_flux_up", bb["flux_up"], seqsum(G["lw_flux_up"]), tol=max(tol, 1e-12))
+        ck.close("lw_bb_flux_dn", bb["flux_dn"], seqsum(G["lw_flux_dn"]), tol=max(tol, 1e-12))
+        bb = be.sw_solver_2stream(*sw, do_broadband=True)
+        for k in ("up", "dn", "dir"):
+            ck.close("sw_bb_flux_" + k, bb["flux_" + k], seqsum(G["sw_flux_" + k]), tol=max(tol, 1e-12))
+        # clear-sky form: g identically zero (HIP: no g array at all -> the hand-folded two-stream coefficients)
+        g0 = None if getattr(be, "supports_null_g", False) else up(np.zeros_like(I["g"]))
+        b0 = be.sw_solver_2stream(sw[0], sw[1], sw[2], g0, *sw[4:], do_broadband=True)
+        for k in ("up", "dn", "dir"):
+            ck.close("sw_bb_g0_flux_" + k, b0["flux_" + k], G["sw_g0_bb_" + k], tol=max(tol, 1e-12))
+    return ck.worst
+
+
+def run_chainbb_case(be, G, tol, **modes):
+    """Atmosphere -> broadband fluxes through pipeline.solve_lw / solve_sw in the backend's default (product) chain, against
+    the reference kernel text's chain at 140 layers."""
+    ck = Checker(be, tol)
+    ncol, nlay, top_at_1, _ = [int(x) for x in G["meta"]]
+    vmr = {k[4:]: G[k] for k in G.files if k.startswith("vmr_")}
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=2, nbnd_sw=2, top_at_1=bool(top_at_1), seed=7)
+    for k in ("p_lay", "p_lev", "t_lay", "t_lev", "t_sfc", "mu0"):
+        assert np.array_equal(getattr(atm0, k), G[k]), f"synthetic atmosphere drifted ({k}): regenerate goldens"
+    for n in vmr:
+        assert np.array_equal(atm0.vmr[n], vmr[n]), n
+    atm = pipeline.upload_atmosphere(be, atm0)
+    for kind in ("lw", "sw"):
+        kd0 = synthetic.make_kdist(kind, **MINI)
+        assert kdist_digest(kd0) == str(G[f"{kind}_kdist_digest"]), "synthetic k-distribution drifted: regenerate goldens"
+        kd = be.upload_kdist(kd0)
+        r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, col_dry=be.asarray(G["col_dry"]), **modes)
+        ck.close(f"{kind}_flux_up", r["flux_up"], G[f"{kind}_flux_up"], tol=max(tol, 1e-12))
+        ck.close(f"{kind}_flux_dn", r["flux_dn"], G[f"{kind}_flux_dn"], tol=max(tol, 1e-12))
+        if kind == "sw":
+            ck.close("sw_flux_dir", r["flux_dn_dir"], G["sw_flux_dir"], tol=max(tol, 1e-12))
+        else:
+            ck.close("lw_flux_net", r["flux_net"], G["lw_flux_net"], tol=max(tol, 1e-11))
+    return ck.worst
+
+
+def run_cloud_case(be, G, tol):
+    """rrx_cloud_optics_{2str,1scl} / the restatement against the reference's own CPU class (src/Cloud_optics.cpp:29-232)."""
+    ck = Checker(be, tol)
+    lut = synthetic.make_cloud_lut(int(G["lut_nbnd"]), str(G["lut_kind"]))
+    assert optics_lut_digest(lut) == str(G["lut_digest"]), "synthetic cloud LUT drifted: regenerate goldens"
+    dt = G["clwp"].dtype
+    l = be.upload_lut({k: (v.astype(dt) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
+    up = be.asarray
+    args = (l, up(G["clwp"]), up(G["ciwp"]), up(G["reliq"]), up(G["deice"]))
+    t2, w2, g2 = be.cloud_optics_2str(*args)
+    ck.close("cloud_tau_2str", t2, G["tau_2str"]); ck.close("cloud_ssa_2str", w2, G["ssa_2str"]); ck.close("cloud_g_2str", g2, G["g_2str"])
+    ck.close("cloud_tau_1scl", be.cloud_optics_1scl(*args), G["tau_1scl"])
+    return ck.worst
+
+
+def optics_lut_digest(lut):
+    h = hashlib.sha256()
+    for k in sorted(lut):
+        h.update(k.encode()); h.update(np.ascontiguousarray(np.asarray(lut[k], dtype=np.float64)).tobytes())
+    return h.hexdigest()
+
+
+def run_aerosol_case(be, G, tol, tmp_dir):
+    """rrx_aerosol_optics / the restatement against the reference's own CPU class (src/Aerosol_optics.cpp:24-224) on the real
+    CAMS tables and on synthetic ones."""
+    ck = Checker(be, tol)
+    lut = real_aerosol_lut(tmp_dir) if str(G["table"]) == "real" else synthetic.make_aerosol_lut(5)
+    assert optics_lut_digest(lut) == str(G["lut_digest"]), "aerosol tables drifted: regenerate goldens"
+    dt = G["rh"].dtype
+    l = be.upload_lut({k: v.astype(dt) for k, v in lut.items()})
+    up = be.asarray
+    tau, ssa, g = be.aerosol_optics(l, [up(G["aermr%02d" % i]) for i in range(1, 12)], up(G["rh"]), up(G["p_lev"]))
+    ck.close("aerosol_tau", tau, G["tau"]); ck.close("aerosol_ssa", ssa, G["ssa"]); ck.close("aerosol_g", g, G["g"])
     return ck.worst
 
 

@@ -33,12 +33,49 @@ def test_oracle_incident_flux_convention_vs_reference_text(path, oracle_f64, ora
     assert worst
 
 
+@pytest.mark.parametrize("path", cases.golden_files("tall_"), ids=os.path.basename)
+def test_oracle_tall_solvers_match_reference(path, oracle_f64):
+    """60 / 140 layers, 17 columns: the layer counts of BASELINE's configs."""
+    worst = cases.run_tall_case(oracle_f64, np.load(path), tol=1e-13)
+    assert worst
+
+
+@pytest.mark.parametrize("path", cases.golden_files("chainbb_"), ids=os.path.basename)
+def test_oracle_whole_chain_at_140_layers_matches_reference(path, oracle_f64):
+    worst = cases.run_chainbb_case(oracle_f64, np.load(path), tol=1e-13)
+    assert worst
+
+
+@pytest.mark.parametrize("path", cases.golden_files("cloud_"), ids=os.path.basename)
+def test_oracle_cloud_optics_matches_reference_cpu_class(path, oracle_f64, oracle_f32):
+    """Pins the restatement of src/Cloud_optics.cpp:29-232 to the reference's own class, compiled unmodified
+    (oracle/refcpu_runner.cpp)."""
+    G = np.load(path)
+    be = oracle_f64 if G["clwp"].dtype == np.float64 else oracle_f32
+    worst = cases.run_cloud_case(be, G, tol=1e-13 if be is oracle_f64 else 2e-6)
+    assert worst
+
+
+@pytest.mark.parametrize("path", cases.golden_files("aerosol_"), ids=os.path.basename)
+def test_oracle_aerosol_optics_matches_reference_cpu_class(path, tmp_path, oracle_f64, oracle_f32):
+    """Pins the restatement of src/Aerosol_optics.cpp:24-224 to the reference's own class, compiled unmodified, on the real
+    CAMS tables and on synthetic ones."""
+    G = np.load(path)
+    be = oracle_f64 if G["rh"].dtype == np.float64 else oracle_f32
+    worst = cases.run_aerosol_case(be, G, 1e-13 if be is oracle_f64 else 2e-6, tmp_path)
+    assert worst
+
+
 def test_golden_set_is_complete():
     names = {os.path.basename(p) for p in cases.golden_files("")}
     for tag in ("f64", "f32"):
         for top in (0, 1):
             assert f"chain_{tag}_top{top}.npz" in names and f"random_{tag}_top{top}.npz" in names
             assert f"glue_{tag}_top{top}.npz" in names
+        for n in (f"cloud_{tag}_lw.npz", f"cloud_{tag}_sw.npz", f"aerosol_{tag}_real.npz", f"aerosol_{tag}_synthetic.npz"):
+            assert n in names
+    for top in (0, 1):
+        assert {f"tall_f64_top{top}_nlay60.npz", f"tall_f64_top{top}_nlay140.npz", f"chainbb_f64_top{top}_17x140.npz"} <= names
 
 
 @pytest.mark.parametrize("top_at_1", [False, True])
