@@ -651,8 +651,8 @@ bool launch_scan_bb(hipStream_t st,
     if (need > 12) return false;
     const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
-    const int nsplit = broadband_gsplit(groups, ngpt);
-    const int gper = ceil_div(ngpt, nsplit);
+    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
+    const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     StreamScratch scratch(st);
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;

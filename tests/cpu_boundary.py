@@ -1,0 +1,95 @@
+"""Test-side bindings of the PRODUCT's CPU boundary, rte-rrtmgp-cpp_amd/lib/librrtmgp_kernels_hip.so (include/rrtmgp_kernels.h:
+the 19 bind(C) names of the reference's CPU path, host arrays in and out, computed by the HIP device layer), and of the two
+runner executables that put the reference's own unmodified CPU classes on top of a boundary library (oracle/ref_rte_runner.cpp).
+
+The marshalling is the oracle binding's (same names, same pointer convention: that is the point of the boundary), so the golden
+replays of tests/cases.py run unchanged on it."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+import oracle_py
+from rte_rrtmgp_cpp_amd._ffi import Lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ("rte_sum_broadband", "rte_net_broadband_precalc", "sum_byband", "net_byband_precalc", "zero_array_3D", "zero_array_4D",
+         "rrtmgp_interpolation", "rrtmgp_compute_tau_absorption", "reorder_123x321_kernel", "combine_and_reorder_2str",
+         "rrtmgp_compute_Planck_source", "rrtmgp_compute_tau_rayleigh", "rte_lw_solver_noscat", "rte_sw_solver_2stream",
+         "rte_increment_2stream_by_2stream", "rte_increment_1scalar_by_1scalar", "rte_inc_2stream_by_2stream_bybnd",
+         "rte_inc_1scalar_by_1scalar_bybnd", "rte_delta_scale_2str_k")
+
+
+def lib_path(dtype=np.float64):
+    sfx = "" if np.dtype(dtype) == np.float64 else "_sp"
+    return os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", f"librrtmgp_kernels_hip{sfx}.so")
+
+
+class HipCpuBoundary(oracle_py.CpuKernels):
+    """The 19 boundary names only: the host-class helpers the oracle adds (get_col_dry, cloud optics, ...) are not part of it."""
+
+    def __init__(self, dtype=np.float64):
+        self.kind = "oracle"                 # pointer convention + broadband semantics of the CPU path
+        self.name = "hipcpu"
+        self.np_dtype = np.dtype(dtype)
+        self.lib = Lib(lib_path(dtype), self.np_dtype, by_ref=True)
+
+    def __getattribute__(self, item):
+        if item in ("get_col_dry", "expand_and_transpose", "cloud_optics_1scl", "cloud_optics_2str", "aerosol_optics", "net_byband_full"):
+            raise AttributeError(item)
+        return object.__getattribute__(self, item)
+
+    def combine_abs_and_rayleigh(self, tau_abs, tau_ray):
+        # combine_and_reorder_2str takes (ngpt,nlay,ncol)-ordered inputs (g-point fastest) and returns (ncol,nlay,ngpt) outputs
+        ngpt, nlay, ncol = tau_abs.shape
+        tr = lambda a: np.ascontiguousarray(a.transpose(2, 1, 0))
+        tau = self.empty(tau_abs.shape); ssa = self.empty(tau_abs.shape); g = self.empty(tau_abs.shape)
+        self.lib.call("combine_and_reorder_2str", ncol, nlay, ngpt, tr(tau_abs), tr(tau_ray), tau, ssa, g)
+        return tau, ssa, g
+
+    def reorder123x321(self, arr_in):
+        ni, nj, nk = arr_in.shape
+        out = self.empty((nk, nj, ni))
+        self.lib.call("reorder_123x321_kernel", ni, nj, nk, arr_in, out)
+        return out
+
+    def net_byband(self, bnd_dn, bnd_up):
+        nbnd, nlev, ncol = bnd_dn.shape
+        out = self.empty(bnd_dn.shape)
+        self.lib.call("net_byband_precalc", ncol, nlev, nbnd, bnd_dn, bnd_up, out)
+        return out
+
+
+def runner(which):
+    return os.path.join(ROOT, "oracle", "_ref", "ref_rte_" + which)
+
+
+def run_reference_classes(which, kind, dims, arrays, band_lims_gpt, top_at_1, broadband=False, n_angles=1, has_inc=False,
+                          has_bybnd=False, delta=False):
+    """Reference Rte_lw / Rte_sw / Fluxes_broadband / add_to / delta_scale (unmodified sources) on boundary library `which`
+    ("oracle" or "hip"). dims = (ncol, nlay, ngpt, nbnd); arrays in the order oracle/ref_rte_runner.cpp reads them, numpy C order
+    with the column last. Returns the list of output arrays in the runner's order."""
+    ncol, nlay, ngpt, nbnd = dims
+    ints = [ncol, nlay, ngpt, nbnd, int(top_at_1), int(broadband), n_angles, int(has_inc), int(has_bybnd), int(delta)]
+    ints += [int(x) for x in np.asarray(band_lims_gpt).reshape(-1)]
+    edges = np.linspace(10., 3250., nbnd + 1)
+    wvn = np.stack([edges[:-1], edges[1:]], axis=1)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([len(ints)] + ints, dtype="<i4").tofile(f)
+            for a in [wvn] + list(arrays):
+                np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+        subprocess.run([runner(which), kind, fin, fout], check=True)
+        flat = np.fromfile(fout, dtype=np.float64)
+    cell, lev, bb = (ngpt, nlay, ncol), (ngpt, nlay+1, ncol), (nlay+1, ncol)
+    if kind == "lw":
+        shapes = [cell] + ([bb, bb] if broadband else [lev, lev, bb, bb, bb])
+    else:
+        shapes = [cell]*3 + ([bb]*3 if broadband else [lev]*3 + [bb]*4)
+    out, pos = [], 0
+    for s in shapes:
+        n = int(np.prod(s)); out.append(flat[pos:pos+n].reshape(s)); pos += n
+    assert pos == flat.size
+    return out

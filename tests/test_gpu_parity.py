@@ -649,6 +649,40 @@ def test_aerosol_optics_and_aerosol_sw_solve_match_oracle(dt, top_at_1, tmp_path
     assert float(np.max(np.abs(a_ - b_)) / np.max(np.abs(b_))) > 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("ngpt", [33, 130])
+def test_split_gpoint_range_never_leaves_an_empty_range(dt, ngpt, hip_f64, hip_f32):
+    """with gper = ceil(ngpt / nsplit) the last ranges were empty when (nsplit - 1) * gper >= ngpt (e.g. 33 or 130
+    g-points), and their workgroups prefetched slabs past the end of the arrays. The launchers now re-derive the number of ranges
+    from gper; checked for the automatic rule and for a forced 16-way split, few columns, LW and SW (with and without g)."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    rng = np.random.default_rng(ngpt)
+    nlay, ncol = 60, 24
+    shp = (ngpt, nlay, ncol)
+    up = lambda a: be.asarray(np.ascontiguousarray(a).astype(be.np_dtype))
+    tau = 10.0**rng.uniform(-5, 1.5, shp); ssa = rng.uniform(0, 1, shp); g = rng.uniform(0, .9, shp)
+    lay = rng.uniform(5, 40, shp); lev = rng.uniform(5, 40, (ngpt, nlay+1, ncol))
+    e2 = rng.uniform(.5, 1, (ngpt, ncol)); mu0 = rng.uniform(.1, 1, ncol)
+    sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+
+    def run():
+        l = be.lw_solver_noscat(True, sec, w, up(tau), up(lay), up(lev), up(e2), up(e2*20), do_broadband=True)
+        s = be.sw_solver_2stream(True, up(tau), up(ssa), up(g), up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=True)
+        s0 = be.sw_solver_2stream(True, up(tau), up(ssa), None, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=True)
+        return [be.to_numpy(x) for x in (l["flux_up"], l["flux_dn"], s["flux_up"], s["flux_dn"], s["flux_dir"], s0["flux_up"], s0["flux_dir"])]
+
+    try:
+        be.set_broadband_min_groups(1); be.set_broadband_gsplit(1)
+        ref = run()
+        be.set_broadband_min_groups(512)
+        for split in (0, 16, 7):
+            be.set_broadband_gsplit(split)
+            for a, b in zip(run(), ref):
+                assert cases.rel_err(a, b) <= (1e-13 if dt == "f64" else 5e-6), split
+    finally:
+        be.set_broadband_min_groups(512); be.set_broadband_gsplit(0)
+
+
 def test_rccl_allgather_fluxes_c_abi(hip_f64):
     """include/rrx_rccl.h: (i) the pad / place kernels reproduce a column-sharded array for several world sizes, including
     uneven splits (layout check on one device); (ii) a real communicator of one rank: rrx_allgather_fluxes is the identity."""
