@@ -197,7 +197,8 @@ void reorder_123x321_kernel(int* dim1, int* dim2, int* dim3, Float* array, Float
     const size_t n = sz(*dim1, *dim2, *dim3);
     const Float* a = S.in(array, n);
     Float* o = S.out(array_out, n);
-    RRX_K(rrx_reorder123x321, *dim1, *dim2, *dim3, a, o);
+    // the device launcher names the dimensions of its OUTPUT (ni fastest there; gas_optics_rrtmgp_kernels.cu:76-90), Fortran those of the input
+    RRX_K(rrx_reorder123x321, *dim3, *dim2, *dim1, a, o);
     S.finish();
 }
 
@@ -209,8 +210,8 @@ void combine_and_reorder_2str(int* ncol, int* nlay, int* ngpt, Float* tau_local,
     const size_t n = sz(*ncol, *nlay, *ngpt);
     const Float* a = S.in(tau_local, n); const Float* r = S.in(tau_rayleigh, n);
     Float* at = S.alloc<Float>(n); Float* rt = S.alloc<Float>(n);
-    RRX_K(rrx_reorder123x321, *ngpt, *nlay, *ncol, a, at);
-    RRX_K(rrx_reorder123x321, *ngpt, *nlay, *ncol, r, rt);
+    RRX_K(rrx_reorder123x321, *ncol, *nlay, *ngpt, a, at);
+    RRX_K(rrx_reorder123x321, *ncol, *nlay, *ngpt, r, rt);
     Float* d_tau = S.out(tau, n); Float* d_ssa = S.out(ssa, n); Float* d_g = S.out(g, n);
     RRX_K(rrx_combine_abs_and_rayleigh, *ncol, *nlay, *ngpt, at, rt, d_tau, d_ssa, d_g);
     S.finish();

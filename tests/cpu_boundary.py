@@ -49,9 +49,9 @@ class HipCpuBoundary(oracle_py.CpuKernels):
         return tau, ssa, g
 
     def reorder123x321(self, arr_in):
-        ni, nj, nk = arr_in.shape
+        ni, nj, nk = arr_in.shape            # numpy C order: the Fortran array is (nk, nj, ni) = (dim1, dim2, dim3)
         out = self.empty((nk, nj, ni))
-        self.lib.call("reorder_123x321_kernel", ni, nj, nk, arr_in, out)
+        self.lib.call("reorder_123x321_kernel", nk, nj, ni, arr_in, out)
         return out
 
     def net_byband(self, bnd_dn, bnd_up):

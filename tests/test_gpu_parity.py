@@ -15,6 +15,9 @@ from rte_rrtmgp_cpp_amd import synthetic, pipeline
 
 pytestmark = pytest.mark.gpu
 TOL64, TOL32 = 1e-10, 2e-4
+# the windowed gas-optics kernel of the product chain (FMA contraction, Newton reciprocal) against the gather / reference-shaped
+# kernels, which are bit-exact among themselves and pinned to the goldens
+WIN64, WIN32 = 1e-12, 2e-5
 
 
 @pytest.mark.parametrize("path", cases.golden_files("chain_"), ids=os.path.basename)
@@ -522,13 +525,23 @@ def test_direct_gas_optics_equals_interpolation_path(kind, dt, hip_f64, hip_f32)
     atm0.p_lay = np.ascontiguousarray(atm0.p_lay * scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * scale[None, :])
     atm0.t_lay = np.ascontiguousarray(atm0.t_lay + rng.uniform(-10, 10, atm0.ncol)[None, :])
     kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
-    res = []
-    for direct in (False, True):
-        r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, keep=True, direct=direct)
-        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
-    a, b = res
-    for k in ("tau",) + (("lay_src", "lev_src", "sfc_src") if kind == "lw" else ("ssa",)) + ("flux_up", "flux_dn"):
-        assert np.array_equal(a[k], b[k]), f"{kind} {dt} {k}: direct path differs from the interpolation path"
+    keys = ("tau",) + (("lay_src", "lev_src", "sfc_src") if kind == "lw" else ("ssa",)) + ("flux_up", "flux_dn")
+    solve = pipeline.solve_lw if kind == "lw" else pipeline.solve_sw
+    get = lambda r: {k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)}
+    a = get(solve(be, kd, atm, keep=True, direct=False))
+    # gather kernels: the same expressions in the same order -> the same bits
+    be.lib.call("rrx_set_gas_window", 0)
+    try:
+        b = get(solve(be, kd, atm, keep=True, direct=True))
+    finally:
+        be.lib.call("rrx_set_gas_window", 1)
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), f"{kind} {dt} {k}: direct path (gather kernels) differs from the interpolation path"
+    # windowed kernel ahead of them (the product default): FMA-contracted node sums, Newton reciprocal for ssa
+    c = get(solve(be, kd, atm, keep=True, direct=True))
+    for k in keys:
+        e = cases.rel_err(c[k], a[k], floor=1e-6 if dt == "f64" else 1e-2)
+        assert e <= (WIN64 if dt == "f64" else WIN32), f"{kind} {dt} {k}: windowed direct path {e:.2e} from the interpolation path"
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
@@ -575,8 +588,9 @@ def test_planck_lite_chain(dt, top_at_1, hip_f64, hip_f32):
 def test_windowed_gas_optics_and_fused_fractions(dt, hip_f64, hip_f32):
     """The windowed kernels (LUT boxes staged in LDS) against the gather kernels they replace, on an atmosphere where most
     workgroups take the windowed path and some are handed back (tropopause rows, a few columns far off in pressure): optical
-    depths and single-scattering albedo bit for bit (same expressions, same order); rrx_gas_optics_lw_fractions = tau +
-    Planck-lite outputs in one pass, bit for bit against rrx_gas_optics_lw_direct + rrx_planck_fractions."""
+    depths and single-scattering albedo to 1e-12 (the windowed kernel contracts its node sums into FMAs; handed-back workgroups
+    are the gather kernel's bits); rrx_gas_optics_lw_fractions = tau + Planck-lite outputs in one pass against
+    rrx_gas_optics_lw_direct + rrx_planck_fractions."""
     be = hip_f64 if dt == "f64" else hip_f32
     N = be.to_numpy
     rng = np.random.default_rng(31)
@@ -601,15 +615,19 @@ def test_windowed_gas_optics_and_fused_fractions(dt, hip_f64, hip_f32):
                 outs.append([N(tau), N(ssa), N(g)])
         be.lib.call("rrx_set_gas_window", 1)
         for a_, b_ in zip(*outs):
-            assert np.array_equal(a_, b_), f"{kind} {dt}: windowed kernel differs from the gather kernel"
+            e = cases.rel_err(a_, b_, floor=1e-6 if dt == "f64" else 1e-2)
+            assert e <= (WIN64 if dt == "f64" else WIN32), f"{kind} {dt}: windowed kernel {e:.2e} from the gather kernel"
         if kind == "lw":
             sfc_lay = pipeline._sfc_lay(atm)
             fr_ref = be.planck_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas)
             tau2 = be.empty(shape)
             fr = be.gas_optics_lw_fractions(kd, atm.p_lay, atm.t_lay, atm.t_lev, atm.t_sfc, sfc_lay, col_gas, tau2)
-            assert np.array_equal(N(tau2), outs[0][0])
-            for k in ("pfrac", "blay", "blev", "sfc_src", "sfc_src_jac"):
+            assert np.array_equal(N(tau2), outs[0][0])          # the fractions form and the plain windowed form: same expressions
+            for k in ("blay", "blev"):
                 assert np.array_equal(N(fr[k]), N(fr_ref[k])), k
+            for k in ("pfrac", "sfc_src", "sfc_src_jac"):
+                e = cases.rel_err(N(fr[k]), N(fr_ref[k]), floor=1e-6 if dt == "f64" else 1e-2)
+                assert e <= (WIN64 if dt == "f64" else WIN32), (k, e)
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
