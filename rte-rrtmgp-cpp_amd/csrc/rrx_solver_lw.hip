@@ -142,7 +142,9 @@ lw_noscat_scan_kernel(
             else         lev_below = lv_next.v[v];
             const F lev_above = lv[j].v[v];
 
-            const F tau_loc = tv.v[v] * D.v[v];
+            // a padding layer (level slot beyond the surface) is made transparent through its optical depth: tau = 0 gives
+            // trans = 1 and fact = 0 (series branch) exactly, hence zero sources -- one select instead of three
+            const F tau_loc = (valid ? tv.v[v] : F(0.)) * D.v[v];
             const F trans = exp(-tau_loc);
             const F fact = tau_loc > tau_thres ?
                 (F(1.) - trans) * fast_rcp(tau_loc) - trans :
@@ -151,9 +153,9 @@ lw_noscat_scan_kernel(
             const F s_dn = omt * lev_below + F(2.) * fact * (ls.v[v] - lev_below);
             const F s_up = omt * lev_above + F(2.) * fact * (ls.v[v] - lev_above);
 
-            tr[j][v]  = valid ? trans : F(1.);
-            sdn[j][v] = valid ? s_dn : F(0.);
-            sup[j][v] = valid ? s_up : F(0.);
+            tr[j][v]  = trans;
+            sdn[j][v] = s_dn;
+            sup[j][v] = s_up;
 
             Bdn[v] = tr[j][v] * Bdn[v] + sdn[j][v];
             Bup[v] += A[v] * sup[j][v];
@@ -498,7 +500,7 @@ lw_noscat_bb_kernel(
             const F lvb = level_src(j+1, v);
             F lsj = cur.a1[j].v[v];
             if constexpr (LITE) lsj *= lds_b[j*V+v][tid];
-            const F tau_loc = tvj * cur.D.v[v];
+            const F tau_loc = (valid ? tvj : F(0.)) * cur.D.v[v];      // padding layer: tau = 0 -> trans = 1, fact = 0, sources 0 (exactly)
             const F trans = exp_neg(-tau_loc);
             const F fact = tau_loc > tau_thres ? (F(1.) - trans) * fast_rcp(tau_loc) - trans
                                                : tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
@@ -506,7 +508,7 @@ lw_noscat_bb_kernel(
             const F s_dn = omt * lvb + F(2.) * fact * (lsj - lvb);
             const F s_up = omt * lva[v] + F(2.) * fact * (lsj - lva[v]);
             lva[v] = lvb;
-            tr[j][v] = valid ? trans : F(1.); sdn[j][v] = valid ? s_dn : F(0.); sup[j][v] = valid ? s_up : F(0.);
+            tr[j][v] = trans; sdn[j][v] = s_dn; sup[j][v] = s_up;
             Bdn[v] = tr[j][v]*Bdn[v] + sdn[j][v];
             Bup[v] += A[v]*sup[j][v];
             A[v] *= tr[j][v];

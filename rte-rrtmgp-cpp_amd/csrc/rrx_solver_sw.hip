@@ -247,12 +247,15 @@ sw_2stream_scan_kernel(
                 const int e = j*V + v - BB_EVALS;             // the evaluation this one waits for
                 if (e >= 0) asm volatile("" : "+v"(tv.v[v]) : "v"(qb[e / V][e % V]));
             }
-            const TwoStream<F> ts = two_stream<F,GZ>(tv.v[v], wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
-            rp[j][v] = valid ? ts.r_dif : F(0.);
-            al[j][v] = valid ? ts.t_dif : F(1.);
-            sb[j][v] = valid ? ts.r_dir : F(0.);
-            qb[j][v] = valid ? ts.t_dir : F(0.);
-            lds_dir[j*V+v][tid] = valid ? ts.t_noscat : F(1.);
+            // a padding layer (level slot beyond the surface) is made transparent through its optical depth: tau = 0 gives
+            // r_dif = 0, t_noscat = 1 exactly, t_dif = 1 to an ulp and r_dir = t_dir = the eps floor of the clamps (2e-16 of the
+            // direct beam) -- one select on the input instead of five on the outputs
+            const TwoStream<F> ts = two_stream<F,GZ>(valid ? tv.v[v] : F(0.), wv.v[v], gv.v[v], mu.v[v], mu_inv[v]);
+            rp[j][v] = ts.r_dif;
+            al[j][v] = ts.t_dif;
+            sb[j][v] = ts.r_dir;
+            qb[j][v] = ts.t_dir;
+            lds_dir[j*V+v][tid] = ts.t_noscat;
         }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -541,7 +541,8 @@ def test_direct_gas_optics_equals_interpolation_path(kind, dt, hip_f64, hip_f32)
     c = get(solve(be, kd, atm, keep=True, direct=True))
     for k in keys:
         e = cases.rel_err(c[k], a[k], floor=1e-6 if dt == "f64" else 1e-2)
-        assert e <= (WIN64 if dt == "f64" else WIN32), f"{kind} {dt} {k}: windowed direct path {e:.2e} from the interpolation path"
+        tol = WIN64 if dt == "f64" else (TOL32 if "flux" in k else WIN32)      # fp32 fluxes: round-off through the 140-layer recurrences
+        assert e <= tol, f"{kind} {dt} {k}: windowed direct path {e:.2e} from the interpolation path"
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])

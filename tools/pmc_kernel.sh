@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1] + "/pmc/**/*counter_collection.csv", recursive=Tr
         name = (m.group(1) + "<" + m.group(2) + ">") if m else r["Kernel_Name"][:60]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, d in acc.items():
-    if not any(k in name for k in ("gas_window", "tau_absorption", "planck", "scan_kernel", "bb_kernel")): continue
+    if not any(k in name for k in ("gas_window", "tau_absorption", "planck", "scan_kernel", "bb_kernel", "bb3_kernel")): continue
     print(name, {k: round(sum(v)/len(v)) for k, v in d.items()})
 PY
 find $OUT/pmc -name "*.csv" -size +4M -delete
