@@ -171,14 +171,53 @@ def global_columns(args, world):
     return args.ncol * world if args.scaling == "weak" else args.ncol
 
 
+def spread_columns(atm, spread, col_s, col_e, ntot):
+    """--col-spread s: every column's pressures scaled by U(1-s, 1+s) and its temperatures shifted by
+    U(-30 s, +30 s) K, the spread of tests/test_gpu_parity.py::test_columns_in_different_regimes...; s = 0.35 puts neighbouring
+    columns of a wavefront in different LUT cells and regimes. Column c gets the same values whatever the number of ranks."""
+    rng = np.random.default_rng(4321)
+    scale = rng.uniform(1. - spread, 1. + spread, ntot)[col_s:col_e]
+    dT = rng.uniform(-30.*spread, 30.*spread, ntot)[col_s:col_e]
+    for k in ("p_lay", "p_lev"):
+        setattr(atm, k, np.ascontiguousarray(getattr(atm, k) * scale[None, :]))
+    for k in ("t_lay", "t_lev"):
+        setattr(atm, k, np.ascontiguousarray(getattr(atm, k) + dT[None, :]))
+    atm.t_sfc = np.ascontiguousarray(atm.t_sfc + dT)
+    return atm
+
+
 def local_atmosphere(args, nbnd, rank, world):
     """This rank's column range [start, stop) of the job's global synthetic atmosphere (sharding.column_range) and its
     host-side slice. Column c of the job is the same column whatever the number of ranks."""
     from rte_rrtmgp_cpp_amd import synthetic, sharding
     ntot = global_columns(args, world)
     s, e = sharding.column_range(rank, world, ntot)
+    if getattr(args, "allsky", False):     # the all-sky atmosphere (cloud mask) is built as a whole and sharded: see main()
+        return (s, e), None
     # only this rank's columns are built (column c is the same column whatever the number of ranks)
-    return (s, e), synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e))
+    atm = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e))
+    if getattr(args, "col_spread", 0.0) > 0:
+        atm = spread_columns(atm, args.col_spread, s, e, ntot)
+    return (s, e), atm
+
+
+def sources_digest():
+    """sha256 over the device sources: profiles/pmc_traffic.json records the digest its counters were collected with, so that
+    roofline.traffic / roofline_valu can be marked stale once a kernel has changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_is_stale():
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("sources_digest", {}).get("sha256") != sources_digest()
 
 
 def main():
@@ -205,6 +244,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="wait for each all-gather before the next solve starts (A/B of the pipelined exchange)")
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
+    ap.add_argument("--col-spread", type=float, default=0.0,
+                    help="column heterogeneity: pressures x U(1-s,1+s), temperatures + U(-30s,30s) K per column (default 0 = SURVEY 8(d)'s workload)")
     ap.add_argument("--allsky", action="store_true",
                     help="BASELINE's all-sky flow (C5): cloud optics added by band after the gas optics, delta-scaled in SW; not the headline workload")
     args = ap.parse_args()
@@ -253,6 +294,8 @@ def main():
     if args.allsky:
         from rte_rrtmgp_cpp_amd import sharding as _sh
         full = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, clouds=True)
+        if args.col_spread > 0:
+            full = spread_columns(full, args.col_spread, 0, ntot, ntot)
         atm0 = full if world == 1 else _sh.shard_atmosphere(full, rank, world)
         cast = lambda lut: be.upload_lut({k: (v.astype(np_dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
         cloud_luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
@@ -271,6 +314,21 @@ def main():
         one_step()
     if gatherer is not None:
         gatherer.finish()
+    # one untimed step with the windowed gas optics' hand-back census switched on (it synchronises the stream per launch)
+    handed = None
+    if rank == 0 and be.lib.has("rrx_gas_window_stats"):
+        import ctypes
+        os.environ["RRX_GW_STATS"] = "1"
+        be.lib.cdll.rrx_gas_window_stats(None, None, 1)
+        devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(2); os.dup2(devnull, 2)      # (the census also prints to stderr)
+        try:
+            solver.step(); torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 2); os.close(saved); os.close(devnull); del os.environ["RRX_GW_STATS"]
+        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        be.lib.cdll.rrx_gas_window_stats(ctypes.byref(a), ctypes.byref(b), 1)
+        if b.value > 0:
+            handed = {"handed_back": int(a.value), "workgroups": int(b.value), "frac": round(a.value / b.value, 4)}
     solver.enable_stage_events(args.steps)
 
     if world > 1:
@@ -315,6 +373,7 @@ def main():
                        "columns_per_gpu": ncol_local, "columns_total": ntot, "nlay": args.nlay, "ngpt": args.ngpt,
                        "flux_mode": "broadband (do_broadband solvers, g-point sums on chip)" if args.broadband
                                     else "per-g-point fluxes + sum_broadband",
+                       "col_spread": args.col_spread,
                        "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac"], "traffic": pmc_traffic(dom, args),
@@ -323,6 +382,17 @@ def main():
             "stages": kernels,
             "finite": finite,
         }
+        # the PMC-derived entries come from the committed counter summary, not from this run: say so when a kernel has changed since
+        stale = pmc_is_stale()
+        if stale is not None:
+            out["roofline"]["traffic_stale"] = bool(stale)
+            if out["roofline_valu"] is not None:
+                out["roofline_valu"]["stale"] = bool(stale)
+        if handed is not None:
+            out["gas_window"] = handed
+        if world > 1:       # what a SCALE record can be checked against
+            out["ranks_seen"] = dist.get_world_size()
+            out["columns_per_rank"] = [int(e - s) for s, e in (sharding.column_range(r, world, ntot) for r in range(world))]
         if world == 1 and args.cpu_cols > 0 and not args.allsky:      # (the CPU sample is the clear-sky headline workload)
             out["cpu_baseline"] = cpu_baseline(args, kd_lw0, kd_sw0, be)
         print(json.dumps(out), flush=True)

@@ -67,6 +67,9 @@ int rrx_set_broadband_gsplit(int n);
 /* 1 (default): the "direct" gas optics run the windowed kernel (LUT boxes staged in LDS) ahead of the gather kernel;
    0: gather kernel only (A/B runs, tests). Like the other switches it acts on the calling host thread. */
 int rrx_set_gas_window(int on);
+/* diagnostic: with RRX_GW_STATS set in the environment every windowed gas-optics launch waits for its kernel and counts the
+   workgroups it handed back to the gather kernel; this returns (and optionally resets) the calling thread's totals */
+int rrx_gas_window_stats(long long* handed_back, long long* workgroups, int reset);
 
 #define RRX_DECLARE(F, SFX) \
 /* ---- Rte_solver_kernels_cuda : include_kernels_cuda/rte_solver_kernels_cuda.h:33-64 ---- */ \

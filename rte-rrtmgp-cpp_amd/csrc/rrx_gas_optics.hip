@@ -1203,13 +1203,16 @@ inline int gas_window_parts(const int nblk, const int nchunk)
     return nz;
 }
 
-// RRX_GW_STATS=1: after a windowed launch, print how many workgroups were handed back to the gather kernel, and why
+// RRX_GW_STATS=1 (read at every launch, so a host program can switch it on for one solve): after a windowed launch, wait for it,
+// print how many workgroups were handed back to the gather kernel and why, and add them to the calling thread's totals
+// (rrx_gas_window_stats). Diagnostic only: it synchronises the stream.
+thread_local long long g_gw_handed = 0, g_gw_total = 0;
 inline void gas_window_stats(const char* what, const int* todo, const int nblk, hipStream_t st)
 {
-    static const bool on = std::getenv("RRX_GW_STATS") != nullptr;
-    if (!on) return;
+    if (std::getenv("RRX_GW_STATS") == nullptr) return;
     int h[9];
     if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h, todo - 8, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    g_gw_handed += h[8]; g_gw_total += nblk;
     std::fprintf(stderr, "[gas window %s] %d of %d workgroups handed back: temperature %d, pressure %d, regimes %d, chunk form %d, eta %d\n",
                  what, h[8], nblk, h[0], h[1], h[2], h[3], h[4]);
 }
@@ -2245,4 +2248,12 @@ int rrx_zero_array##SFX(int ni, int nj, int nk, F* arr, void* stream) \
 
 RRX_DEFINE_GAS(double, _f64)
 RRX_DEFINE_GAS(float, _f32)
+}
+
+extern "C" int rrx_gas_window_stats(long long* handed_back, long long* workgroups, int reset)
+{
+    if (handed_back) *handed_back = g_gw_handed;
+    if (workgroups) *workgroups = g_gw_total;
+    if (reset) { g_gw_handed = 0; g_gw_total = 0; }
+    return 0;
 }

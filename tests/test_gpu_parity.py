@@ -469,7 +469,23 @@ def test_real_spectral_shape_matches_oracle(kind, top_at_1, hip_f64, oracle_f64)
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
-def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32):
+@pytest.mark.parametrize("flow", ["per-gpoint", "product"])
+def test_c3_allsky_256_gpoints_fp64_matches_oracle(kind, flow, hip_f64, oracle_f64):
+    """BASELINE C3 as stated: all-sky LW+SW with two-stream cloud optics, 128 columns x 72 layers x 256 g-points (16 bands), fp64,
+    against the oracle -- the per-g-point flow and the product chain (clouds fused into the windowed gas optics, fused broadband
+    solvers; VERDICT r02 weak #8)."""
+    kw = dict(delta_cloud=True) if kind == "sw" else {}
+    h, o = _solve_both(hip_f64, oracle_f64, kind, 128, 72, False, True, ngpt=256, nbnd=16, do_broadband=(flow == "product"), **kw)
+    for k in ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ()):
+        e = cases.rel_err(h[k], o[k])
+        assert e <= (1e-7 if kind == "sw" else 1e-9), f"C3 {kind} {flow} {k}: {e:.3e}"
+    if flow == "per-gpoint":
+        for k in ("tau",) + (("ssa", "g") if kind == "sw" else ()):
+            assert cases.rel_err(h[k], o[k]) <= 1e-9, k
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32, oracle_f64):
     """BASELINE C5: all-sky LW+SW in single precision at the real column shape (140 layers x 256 g-points; 192 columns, two
     of every three cloudy): cloud optics (1scl / 2str), delta scaling, the by-band increments and the full solve against the
     fp32 oracle. Tolerances: fp32 round-off through 140-layer recurrences (2e-4); SW fluxes 1e-3 (k_min / resonance clamps
@@ -507,6 +523,28 @@ def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32):
     print(f"C5 fp32 all-sky {kind}: worst rel err", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     for k, e in worst.items():
         assert e <= (1e-3 if (kind == "sw" and "flux" in k) else 2e-4), f"{kind} {k}: {e:.3e}"
+    # broadband fluxes with a floor of 1e-4 instead of 1e-2: the sums over 256 g-points are well conditioned
+    flux_keys = ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ())
+    tight = _worst(h, o, flux_keys, floor=1e-4)
+    print(f"C5 fp32 all-sky {kind}: broadband fluxes, floor 1e-4:", {k: f"{e:.2e}" for k, e in tight.items()})
+    for k, e in tight.items():
+        assert e <= (2e-3 if kind == "sw" else 5e-4), f"{kind} {k} (floor 1e-4): {e:.3e}"
+    # (c) in the unit of the reference's own gate: fp32 HIP broadband fluxes against the fp64 oracle, max |difference| in W m-2
+    # (.github/workflows/continuous-integration.yml:60-62 of the reference accepts 5.8e-2 W m-2 against the reference fluxes)
+    kd64 = oracle_f64.upload_kdist(kd0); atm64 = pipeline.upload_atmosphere(oracle_f64, atm0.astype(np.float64))
+    kw = dict(delta_cloud=True) if kind == "sw" else {}
+    r64 = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(oracle_f64, kd64, atm64, cloud_lut=oracle_f64.upload_lut(lut0), **kw)
+    dmax = {k: float(np.max(np.abs(h[k].astype(np.float64) - np.asarray(r64[k])))) for k in flux_keys}
+    dref = {k: float(np.max(np.abs(o[k].astype(np.float64) - np.asarray(r64[k])))) for k in flux_keys}     # the fp32 ORACLE against the fp64 one
+    print(f"C5 fp32 all-sky {kind}: max |fp32 HIP - fp64 oracle| in W m-2:", {k: f"{v:.2e}" for k, v in dmax.items()},
+          "| fp32 oracle - fp64 oracle:", {k: f"{v:.2e}" for k, v in dref.items()},
+          "| largest flux", f"{float(np.max(np.abs(np.asarray(r64['flux_dn'])))):.1f}")
+    # On this synthetic k-distribution single precision itself moves the fluxes by more than that gate (the reference arithmetic
+    # is discontinuous at eta == 1, gas_optics_rrtmgp_kernels.cu:377-379: a cell that rounds across it changes tau by percents),
+    # the CPU restatement run in fp32 as much as the HIP path. So: the gate where fp32 itself meets it, otherwise no worse than
+    # 1.5 x what the fp32 oracle shows.
+    for k, v in dmax.items():
+        assert v <= max(5.8e-2, 1.5*dref[k]), f"{kind} {k}: fp32 HIP differs from the fp64 oracle by {v:.3e} W m-2 (fp32 oracle: {dref[k]:.3e})"
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])

@@ -38,4 +38,13 @@ if a.json:
             e["write_bytes"] = 1024.0 * sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
         if "SQ_INSTS_VALU" in cs:          # wave-level VALU instructions per launch (bench.py: roofline_valu)
             e["insts_valu"] = sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"])
+    # digest of the device sources the counters belong to (bench.py marks roofline.traffic / roofline_valu stale when it differs)
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(here, "rte-rrtmgp-cpp_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    out["sources_digest"] = {"sha256": h.hexdigest()}
     json.dump(out, open(a.json, "w"), indent=1, sort_keys=True)
