@@ -202,7 +202,8 @@ class Array_gpu
         }
         void release()
         {
-            if (data_ptr != nullptr && owns) rrx_free_async(data_ptr, alloc_stream);
+            // (the thread's stream may have been switched since the allocation, rrx_host::set_stream: ordered after both)
+            if (data_ptr != nullptr && owns) rrx_free_async_ordered(data_ptr, alloc_stream, rrx_host::current_stream());
             data_ptr = nullptr;
         }
         std::array<int,N> dims;

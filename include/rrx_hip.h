@@ -41,6 +41,10 @@ int rrx_free(void* ptr);
    so freed blocks are reused by the next solve and no call synchronises the device; the copies are enqueued on `stream` and awaited */
 int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream);
 int rrx_free_async(void* ptr, void* stream);
+/* release of a block allocated under `alloc_stream` that may have been used under `release_stream` as well: the release stream waits
+   for the allocation stream's work first; falls back to hipFree if the stream-ordered free fails (never leaks). The pool keeps
+   freed blocks for reuse; RRX_POOL_RELEASE_THRESHOLD=<bytes> in the environment caps that (default: keep everything). */
+int rrx_free_async_ordered(void* ptr, void* alloc_stream, void* release_stream);
 int rrx_memcpy_h2d_stream(void* dst, const void* src, unsigned long long bytes, void* stream);
 int rrx_memcpy_d2h_stream(void* dst, const void* src, unsigned long long bytes, void* stream);
 int rrx_memcpy_h2d(void* dst, const void* src, unsigned long long bytes);

@@ -33,7 +33,16 @@ namespace rrx_cdf
         std::ifstream f; int ver;
         uint32_t u32() { unsigned char b[4]; if (!f.read(reinterpret_cast<char*>(b), 4)) throw std::runtime_error("truncated NetCDF header"); return (uint32_t(b[0]) << 24) | (uint32_t(b[1]) << 16) | (uint32_t(b[2]) << 8) | b[3]; }
         uint64_t u64() { const uint64_t hi = u32(); return (hi << 32) | u32(); }
-        std::string name() { const uint32_t n = u32(); std::string s(n, '\0'); f.read(&s[0], n); f.seekg((4 - n % 4) % 4, std::ios::cur); return s; }
+        // names are bounded (NC_MAX_NAME = 256 in the classic format; header fields of a corrupt file must not turn into allocations)
+        std::string name()
+        {
+            const uint32_t n = u32();
+            if (n > 4096) throw std::runtime_error("NetCDF classic: implausible name length in the header (corrupt file?)");
+            std::string s(n, '\0');
+            if (n && !f.read(&s[0], n)) throw std::runtime_error("truncated NetCDF header");
+            f.seekg((4 - n % 4) % 4, std::ios::cur);
+            return s;
+        }
     };
 
     inline size_t type_size(const uint32_t t)
@@ -107,6 +116,7 @@ namespace rrx_cdf
         if (r.ver == 0) throw std::runtime_error(path + " is not a classic NetCDF file");
         r.f.seekg(4);
         const uint32_t numrecs = r.u32();
+        if (numrecs == 0xFFFFFFFFu) throw std::runtime_error("NetCDF classic: " + path + " was left in streaming mode (numrecs = STREAMING): record count unknown");
         std::vector<std::string> dim_names; std::vector<int64_t> dim_len;
         int rec_dim = -1;                                      // the record (unlimited) dimension has length 0 in the header
         {
@@ -136,7 +146,13 @@ namespace rrx_cdf
                 {
                     VarInfo v; v.name = r.name();
                     const uint32_t rank = r.u32();
-                    for (uint32_t d=0; d<rank; ++d) v.dimids.push_back(int(r.u32()));
+                    if (rank > 1024) throw std::runtime_error("NetCDF classic: implausible rank of variable " + v.name);
+                    for (uint32_t d=0; d<rank; ++d)
+                    {
+                        const uint32_t id = r.u32();
+                        if (id >= dim_names.size()) throw std::runtime_error("NetCDF classic: variable " + v.name + " refers to a dimension that does not exist");
+                        v.dimids.push_back(int(id));
+                    }
                     skip_attributes(r);
                     v.type = r.u32(); v.vsize = r.u32(); v.begin = (r.ver == 1) ? uint64_t(r.u32()) : r.u64();
                     v.record = false;
@@ -144,6 +160,10 @@ namespace rrx_cdf
                 }
             }
         }
+        r.f.seekg(0, std::ios::end);
+        const uint64_t file_size = uint64_t(r.f.tellg());
+        for (const auto& v : infos)
+            if (v.begin > file_size) throw std::runtime_error("NetCDF classic: data of variable " + v.name + " starts beyond the end of " + path);
         uint64_t recsize = 0;
         int nrecvars = 0;
         for (auto& v : infos)
@@ -163,6 +183,8 @@ namespace rrx_cdf
             // a single record variable is stored without the padding between records (format quirk)
             const uint64_t stride = (record && nrecvars == 1) ? uint64_t(per_rec)*type_size(type) : recsize;
             const size_t nrec = record ? size_t(numrecs) : 1;
+            // the header's sizes must fit the file before anything is allocated for them
+            if (uint64_t(n)*type_size(type) > file_size) throw std::runtime_error("NetCDF classic: variable " + v.name + " is larger than " + path);
             out.loader = [path, type, begin, record, stride, nrec, per_rec, n](rrxb::Var& var)
             {
                 std::ifstream g(path, std::ios::binary);

@@ -5,6 +5,7 @@
 // (the reference's optical-props launchers put the g-point on threadIdx.x, i.e. strided by ncol*nlay) and moves
 // 16 B per lane where the alignment allows.
 #include <mutex>
+#include <cstdlib>
 #include "rrx_common.h"
 #include "rrx_hip.h"
 
@@ -443,7 +444,10 @@ int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream)
     {
         hipMemPool_t pool;
         RRX_HIP_OK(hipDeviceGetDefaultMemPool(&pool, dev), "rrx_malloc_async");
+        // freed blocks stay in the pool for the next solve; RRX_POOL_RELEASE_THRESHOLD (bytes) caps what the pool keeps when the
+        // GPU is shared with other allocators inside a host model (default: everything)
         unsigned long long keep = ~0ull;
+        if (const char* e = std::getenv("RRX_POOL_RELEASE_THRESHOLD")) keep = std::strtoull(e, nullptr, 10);
         RRX_HIP_OK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep), "rrx_malloc_async");
         configured_device = dev;
     }
@@ -451,6 +455,30 @@ int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream)
     return 0;
 }
 int rrx_free_async(void* ptr, void* stream) { RRX_HIP_OK(hipFreeAsync(ptr, static_cast<hipStream_t>(stream)), "rrx_free_async"); return 0; }
+// Release of a block that was allocated under one stream and may have been used under another (rrx_host::set_stream between the
+// two): the release stream first waits for the work enqueued on the allocation stream, then the block returns to the pool in the
+// release stream's order -- after every use on either stream. A failing stream-ordered free (e.g. a destroyed stream) falls back
+// to hipFree, so the block is never leaked.
+int rrx_free_async_ordered(void* ptr, void* alloc_stream, void* release_stream)
+{
+    if (ptr == nullptr) return 0;
+    hipStream_t a = static_cast<hipStream_t>(alloc_stream), r = static_cast<hipStream_t>(release_stream);
+    bool ok = true;
+    if (a != r)
+    {
+        hipEvent_t ev;
+        ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (ok)
+        {
+            ok = hipEventRecord(ev, a) == hipSuccess && hipStreamWaitEvent(r, ev, 0) == hipSuccess;
+            (void)hipEventDestroy(ev);
+        }
+    }
+    if (ok && hipFreeAsync(ptr, r) == hipSuccess) return 0;
+    (void)hipGetLastError();
+    RRX_HIP_OK(hipFree(ptr), "rrx_free_async_ordered");         // synchronises the device: correct, only slower
+    return 0;
+}
 // host <-> device copies enqueued on `stream` and awaited (the host buffer is consumed / filled when the call returns)
 int rrx_memcpy_h2d_stream(void* dst, const void* src, unsigned long long bytes, void* stream)
 {

@@ -7,7 +7,10 @@
 // --ngpus=N: the process becomes the launcher of N ranks of itself, one per GPU; rank r solves the contiguous column
 // range rrx_column_range(r, N, ncol), the broadband (and optional band / optical) outputs are all-gathered over RCCL
 // (include/rrx_rccl.h, librrx_rccl.so loaded on demand) and rank 0 writes the output file.
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
+#include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -142,7 +145,13 @@ namespace
         if (const char* e = std::getenv("RRX_DRIVER_EXE")) exe = e;
         else if (exe.find("test_rte_rrtmgp_gpu") == std::string::npos) exe = Ranks::library_dir() + "/test_rte_rrtmgp_gpu";   // called through the library
         if (access(exe.c_str(), X_OK) != 0) throw std::runtime_error("multi-GPU run needs the stand-alone driver binary, not found: " + exe);
-        const std::string id_file = "/tmp/rrx_comm_" + std::to_string(getpid()) + ".id";
+        // rendezvous file of the communicator id: a name nobody can predict (mkstemp), removed again so that the ranks see it appear
+        char id_tmpl[] = "/tmp/rrx_comm_XXXXXX";
+        const int id_fd = mkstemp(id_tmpl);
+        if (id_fd < 0) throw std::runtime_error("cannot create the rendezvous file of the communicator id");
+        close(id_fd);
+        const std::string id_file = std::string(id_tmpl) + ".id";
+        std::remove(id_tmpl);
         std::remove(id_file.c_str());
         std::vector<pid_t> pids;
         for (int r=0; r<n; ++r)
@@ -162,16 +171,42 @@ namespace
             argvp.push_back(nullptr);
             pid_t pid;
             if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argvp.data(), envp.data()) != 0)
+            {
+                for (const pid_t p : pids) kill(p, SIGTERM);
+                for (const pid_t p : pids) waitpid(p, nullptr, 0);
                 throw std::runtime_error("cannot start rank " + std::to_string(r));
+            }
             pids.push_back(pid);
         }
+        // Reap in completion order. A rank that fails (non-zero exit, signal) leaves the others blocked for ever in
+        // ncclCommInitRank / ncclAllGather, which have no timeout: the survivors are terminated (SIGTERM, then SIGKILL after a
+        // grace period) and the launcher reports the failure instead of hanging.
         int worst = 0;
-        for (const pid_t pid : pids)
+        size_t left = pids.size();
+        bool failed = false;
+        while (left > 0)
         {
             int st = 0;
-            waitpid(pid, &st, 0);
-            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+            const pid_t done = waitpid(-1, &st, 0);
+            if (done < 0) { if (errno == EINTR) continue; break; }
+            const auto it = std::find(pids.begin(), pids.end(), done);
+            if (it == pids.end()) continue;                       // not one of ours
+            *it = -1; --left;
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
             worst = std::max(worst, rc);
+            if (rc != 0 && !failed)
+            {
+                failed = true;
+                Status::print_error("rank process " + std::to_string(int(done)) + " failed (status " + std::to_string(rc) + "): stopping the other ranks");
+                for (const pid_t p : pids) if (p > 0) kill(p, SIGTERM);
+                for (int tick=0; tick<50 && left > 0; ++tick)     // up to 5 s for a clean exit
+                {
+                    for (pid_t& p : pids)
+                        if (p > 0 && waitpid(p, &st, WNOHANG) == p) { p = -1; --left; }
+                    if (left > 0) usleep(100000);
+                }
+                for (const pid_t p : pids) if (p > 0) kill(p, SIGKILL);
+            }
         }
         std::remove(id_file.c_str());
         return worst;

@@ -139,3 +139,24 @@ def test_classic_netcdf_reader(version, nrecvars, tmp_path):
     assert lib.rrx_host_netcdf_get_attr(path.encode(), b"pres", b"units", buf, 64) == 4 and buf.value == b"1e-6"
     assert lib.rrx_host_netcdf_get_attr(path.encode(), b"", b"title", buf, 64) > 0 and buf.value.startswith(b"written by")
     assert lib.rrx_host_netcdf_get_attr(path.encode(), b"pres", b"nope", buf, 64) == -1
+
+
+def test_ngpus_launcher_stops_the_survivors_when_a_rank_fails(tmp_path):
+    """`test_rte_rrtmgp_gpu --ngpus=N` reaps its ranks in completion order; when one fails, the others (which would
+    wait for ever in ncclCommInitRank / ncclAllGather) are terminated and the launcher exits non-zero. The rank executable is
+    replaced by a script (RRX_DRIVER_EXE): rank 1 fails at once, the others would sleep for a minute. No GPU involved."""
+    import subprocess
+    import time
+    exe = os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "test_rte_rrtmgp_gpu")
+    script = tmp_path / "rank.sh"
+    script.write_text("#!/bin/bash\ntest -n \"$RRX_COMM_FILE\" || exit 9\nif [ \"$RRX_RANK\" = 1 ]; then exit 7; fi\nexec sleep 60\n")
+    script.chmod(0o755)
+    env = dict(os.environ, RRX_DRIVER_EXE=str(script))
+    t0 = time.time()
+    r = subprocess.run([exe, "--ngpus=3"], env=env, capture_output=True, text=True, timeout=50)
+    assert r.returncode == 7, (r.returncode, r.stderr[-300:])
+    assert time.time() - t0 < 20, "the launcher waited for the sleeping ranks"
+    assert "stopping the other ranks" in (r.stdout + r.stderr)
+    # all ranks fine: exit status 0
+    script.write_text("#!/bin/bash\nexit 0\n")
+    assert subprocess.run([exe, "--ngpus=3"], env=env, timeout=50).returncode == 0
