@@ -282,7 +282,7 @@ tau_absorption_kernel(
         const int* __restrict__ jeta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
         const F* __restrict__ krayl,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const InterpArgs<F> ia,
-        const int* __restrict__ todo = nullptr, const int todo_gx = 1, const int todo_nblk = 1, const int todo_nz = 1)
+        const int* __restrict__ todo = nullptr, const int todo_gx = 1, const int todo_nblk = 1, const int todo_nz = 1, const int todo_geom = 0)
 {
     // todo != null: this launch finishes the workgroups the windowed kernel handed back (gas_window_kernel): a 1-D grid, block b
     // takes over entry todo[1+b] = workgroup + part * todo_nblk of the (todo_gx x . x todo_nz) grid -- a part is a share of the
@@ -334,8 +334,9 @@ tau_absorption_kernel(
     const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gflav, ngpt, mmeta, nminorlower, nminorupper);
     __syncthreads();
 
-    const int icol = blk_x*blockDim.x + threadIdx.x;
-    const int ilay = blk_y*blockDim.y + threadIdx.y;
+    // (todo_geom 1: the handed-back workgroup was 256 columns of one layer, see gas_window_geometry)
+    const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*blockDim.x + threadIdx.x;
+    const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
 
     const size_t ncl = size_t(ncol)*nlay;
@@ -1058,7 +1059,7 @@ planck_fraction_kernel(
         const F totplnk_delta, const F* __restrict__ totplnk, const int* __restrict__ gpoint_flavor,
         F* __restrict__ pfrac_out, F* __restrict__ blay_out, F* __restrict__ blev_out,
         F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1,
-        const int todo_nblk = 1, const int todo_nz = 1)
+        const int todo_nblk = 1, const int todo_nz = 1, const int todo_geom = 0)
 {
     int blk_x = blockIdx.x, blk_y = blockIdx.y;             // todo: see tau_absorption_kernel
     int g_lo = 0, g_hi = ngpt;
@@ -1076,8 +1077,8 @@ planck_fraction_kernel(
         lds_gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
     __syncthreads();
 
-    const int icol = blk_x*64 + threadIdx.x;
-    const int ilay = blk_y*blockDim.y + threadIdx.y;
+    const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*64 + threadIdx.x;
+    const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
     if (icol >= ncol || ilay >= nlay) return;
     const size_t ncl = size_t(ncol)*nlay;
     const size_t ncv = size_t(ncol)*(nlay+1);
@@ -1203,6 +1204,20 @@ inline int gas_window_parts(const int nblk, const int nchunk)
     return nz;
 }
 
+// Workgroup shape of the windowed kernel: 256 cells that share LUT boxes. 64 columns x 4 layers (geom 0) put a regime change or a
+// jump of the binary-species parameter BETWEEN the layers of one workgroup (at C4: 512 of 8 960 workgroups handed back, 0.8 ms of
+// gather kernels per step); 256 columns x 1 layer (geom 1) have no vertical neighbours to disagree with and at C4 every workgroup
+// fits its boxes. The wide shape is taken when the columns fill it; RRX_GW_GEOM=0/1 overrides (A/B runs).
+inline int gas_window_geometry(const int ncol)
+{
+    if (const char* e = std::getenv("RRX_GW_GEOM")) return std::atoi(e) ? 1 : 0;
+    return ncol >= 192 ? 1 : 0;
+}
+inline dim3 gas_window_grid(const int geom, const int ncol, const int nlay)
+{
+    return geom ? dim3(ceil_div(ncol, 256), nlay) : dim3(ceil_div(ncol, 64), ceil_div(nlay, 4));
+}
+
 // RRX_GW_STATS=1 (read at every launch, so a host program can switch it on for one solve): after a windowed launch, wait for it,
 // print how many workgroups were handed back to the gather kernel and why, and add them to the calling thread's totals
 // (rrx_gas_window_stats). Diagnostic only: it synchronises the stream.
@@ -1251,7 +1266,7 @@ gas_window_kernel(
         const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
         const F* __restrict__ krayl, const InterpArgs<F> ia,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const PlanckArgs<F> pa,
-        int* __restrict__ todo)
+        int* __restrict__ todo, const int geom)
 {
     // The product chain's kernel: multiply-adds of the node sums are contracted into FMAs here and the single-scattering albedo
     // uses a Newton reciprocal (one rounding fewer per term: 1e-15 relative from the gather / reference-shaped kernels, which
@@ -1329,8 +1344,10 @@ gas_window_kernel(
         cuni[w] = (ok && cnt <= NCW) ? 1 : 0;
     }
 
-    const int icol_raw = blockIdx.x*64 + threadIdx.x;
-    const int ilay_raw = blockIdx.y*4 + threadIdx.y;
+    // geom 0: the workgroup's four waves are four consecutive layers of 64 columns; geom 1: four 64-column stretches of ONE layer
+    // (gas_window_geometry: no workgroup straddles the tropopause or an eta jump between layers then)
+    const int icol_raw = geom ? (blockIdx.x*4 + threadIdx.y)*64 + threadIdx.x : blockIdx.x*64 + threadIdx.x;
+    const int ilay_raw = geom ? int(blockIdx.y) : blockIdx.y*4 + threadIdx.y;
     const bool active = icol_raw < ncol && ilay_raw < nlay;
     const int icol = min(icol_raw, ncol-1), ilay = min(ilay_raw, nlay-1);     // inactive threads shadow a valid cell (no stores)
     const size_t ncl = size_t(ncol)*nlay;
@@ -1776,7 +1793,9 @@ int gas_optics_lw_fractions_impl(
     const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, 2, true);
     const bool windowed = tuning().go_window && wlds <= 64*1024;
     StreamScratch scratch(st);
-    const int nblk = int(grid.x)*int(grid.y);
+    const int geom = gas_window_geometry(ncol);
+    const dim3 wgrid = gas_window_grid(geom, ncol, nlay);
+    const int nblk = windowed ? int(wgrid.x)*int(wgrid.y) : int(grid.x)*int(grid.y);
     const int nz = gas_window_parts(nblk, nchunk);
     int* todo = nullptr;
     if (windowed)
@@ -1790,9 +1809,9 @@ int gas_optics_lw_fractions_impl(
                 scale_by_complement_lower, scale_by_complement_upper, \
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                 kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia, \
-                tau, (F*)nullptr, (F*)nullptr, pa, todo
-        if (ia.cld_tau != nullptr) gas_window_kernel<F,2,true,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
-        else gas_window_kernel<F,2,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
+                tau, (F*)nullptr, (F*)nullptr, pa, todo, geom
+        if (ia.cld_tau != nullptr) gas_window_kernel<F,2,true,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
+        else gas_window_kernel<F,2,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
 #undef RRX_GW_PF_ARGS
         gas_window_stats("lw + fractions", todo, nblk*nz, st);
     }
@@ -1805,13 +1824,13 @@ int gas_optics_lw_fractions_impl(
             kminor_start_lower, kminor_start_upper, \
             (const Bool*)nullptr, (const F*)nullptr, (const F*)nullptr, (const F*)nullptr, play, tlay, col_gas, (const F*)nullptr, \
             (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const F*)nullptr, \
-            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(grid.x), nblk, nz
+            tau, (F*)nullptr, (F*)nullptr, ia, todo, int(wgrid.x), nblk, nz, windowed ? geom : 0
     if (ia.cld_tau != nullptr) tau_absorption_kernel<F,2,true,true><<<g2, block, lds, st>>>(RRX_TA_PF_ARGS);
     else tau_absorption_kernel<F,2,true><<<g2, block, lds, st>>>(RRX_TA_PF_ARGS);
 #undef RRX_TA_PF_ARGS
     planck_fraction_kernel<F><<<g2, block, size_t(2)*ngpt*sizeof(int), st>>>(
             ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, play, tlay, tlev, tsfc, sfc_lay, col_gas, ia, gpoint_bands, pfracin,
-            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(grid.x), nblk, nz);
+            totplnk_delta, totplnk, gpoint_flavor, pfrac, blay, blev, sfc_src, sfc_src_jac, todo, int(wgrid.x), nblk, nz, windowed ? geom : 0);
     RRX_CATCH("rrx_gas_optics_lw_fractions")
 }
 
@@ -1849,7 +1868,9 @@ int tau_absorption_impl(
         {
             hipStream_t st = static_cast<hipStream_t>(stream);
             StreamScratch scratch(st);
-            const int nblk = int(grid.x)*int(grid.y);
+            const int geom = gas_window_geometry(ncol);
+            const dim3 wgrid = gas_window_grid(geom, ncol, nlay);
+            const int nblk = int(wgrid.x)*int(wgrid.y);
             const int nz = gas_window_parts(nblk, nchunk);
             int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
@@ -1859,7 +1880,7 @@ int tau_absorption_impl(
                     scale_by_complement_lower, scale_by_complement_upper, \
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                     kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g, \
-                    PlanckArgs<F>(), todo
+                    PlanckArgs<F>(), todo, geom
 #define RRX_TA_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
                     minor_scales_with_density_lower, minor_scales_with_density_upper, \
@@ -1867,13 +1888,13 @@ int tau_absorption_impl(
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                     kminor_start_lower, kminor_start_upper, \
                     tropo, col_mix, fmajor, fminor, play, tlay, col_gas, col_dry, jeta, jtemp, jpress, krayl, \
-                    tau, ssa, g, ia, todo, int(grid.x), nblk, nz
+                    tau, ssa, g, ia, todo, int(wgrid.x), nblk, nz, geom
             const bool cld = DIRECT && MODE != 0 && ia.cld_tau != nullptr;
             if constexpr (DIRECT && MODE != 0)
             {
-                if (cld) gas_window_kernel<F,MODE,false,true><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
+                if (cld) gas_window_kernel<F,MODE,false,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
             }
-            if (!cld) gas_window_kernel<F,MODE,false><<<dim3(grid.x, grid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
+            if (!cld) gas_window_kernel<F,MODE,false><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_ARGS);
             gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk*nz, st);
             if constexpr (DIRECT && MODE != 0)
             {

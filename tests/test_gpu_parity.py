@@ -579,7 +579,8 @@ def test_direct_gas_optics_equals_interpolation_path(kind, dt, hip_f64, hip_f32)
     c = get(solve(be, kd, atm, keep=True, direct=True))
     for k in keys:
         e = cases.rel_err(c[k], a[k], floor=1e-6 if dt == "f64" else 1e-2)
-        tol = WIN64 if dt == "f64" else (TOL32 if "flux" in k else WIN32)      # fp32 fluxes: round-off through the 140-layer recurrences
+        # fluxes: the 1e-15 differences of tau and the fractions pass through the 140-layer recurrences (small fluxes at the top)
+        tol = (TOL64 if "flux" in k else WIN64) if dt == "f64" else (TOL32 if "flux" in k else WIN32)
         assert e <= tol, f"{kind} {dt} {k}: windowed direct path {e:.2e} from the interpolation path"
 
 
