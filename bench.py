@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the independent LW and SW chains on two HIP streams")
     ap.add_argument("--col-spread", type=float, default=0.0,
                     help="column heterogeneity: pressures x U(1-s,1+s), temperatures + U(-30s,30s) K per column (default 0 = SURVEY 8(d)'s workload)")
+    ap.add_argument("--sort-columns", default=None, choices=["auto", "0", "1"],
+                    help="process the columns in ascending order of surface pressure (auto: when neighbouring columns differ; see pipeline.ResidentSolver)")
     ap.add_argument("--allsky", action="store_true",
                     help="BASELINE's all-sky flow (C5): cloud optics added by band after the gas optics, delta-scaled in SW; not the headline workload")
     args = ap.parse_args()
@@ -301,7 +303,8 @@ def main():
         cloud_luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
     ncol_local = col_e - col_s
     atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
-    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts)
+    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts,
+                                     sort_columns=args.sort_columns)
     do_gather = world > 1 and not args.no_gather
     gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
 
@@ -373,7 +376,7 @@ def main():
                        "columns_per_gpu": ncol_local, "columns_total": ntot, "nlay": args.nlay, "ngpt": args.ngpt,
                        "flux_mode": "broadband (do_broadband solvers, g-point sums on chip)" if args.broadband
                                     else "per-g-point fluxes + sum_broadband",
-                       "col_spread": args.col_spread,
+                       "col_spread": args.col_spread, "columns_sorted": bool(solver.sort_columns),
                        "parallelism": f"columns sharded x{world}, all-gather of broadband fluxes"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["frac"], "traffic": pmc_traffic(dom, args),

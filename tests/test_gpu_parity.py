@@ -468,6 +468,39 @@ def test_real_spectral_shape_matches_oracle(kind, top_at_1, hip_f64, oracle_f64)
         assert e <= (1e-7 if kind == "sw" else 1e-9), f"broadband flow {kind} {k}: {e:.3e}"
 
 
+def test_sorted_column_order_gives_the_same_columns(hip_f64):
+    """pipeline.ResidentSolver(sort_columns=...): columns whose pressures differ by +-35 % (bench.py --col-spread 0.35), processed
+    in ascending order of surface pressure and scattered back, against the plain order: every column is computed by the same
+    arithmetic, only the kernel that serves it (windowed / gather) may differ -> 1e-12 on the broadband fluxes. "auto" must switch
+    the sorting on for these columns and leave it off for the benchmark's homogeneous atmosphere; all-sky inputs are permuted too."""
+    be = hip_f64
+    ncol, nlay, ngpt, nbnd = 1024, 140, 64, 4
+    kw = dict(ngpt=ngpt, nbnd=nbnd, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
+    kd_lw = be.upload_kdist(synthetic.make_kdist("lw", **kw)); kd_sw = be.upload_kdist(synthetic.make_kdist("sw", **kw))
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, clouds=True, seed=5)
+    homogeneous = pipeline.upload_atmosphere(be, atm0)
+    assert pipeline.ResidentSolver(be, kd_lw, kd_sw, homogeneous, do_broadband=True).sort_columns is False
+    rng = np.random.default_rng(6)
+    scale = rng.uniform(0.65, 1.35, ncol); dT = rng.uniform(-10, 10, ncol)
+    atm0.p_lay = np.ascontiguousarray(atm0.p_lay*scale[None, :]); atm0.p_lev = np.ascontiguousarray(atm0.p_lev*scale[None, :])
+    atm0.t_lay = np.ascontiguousarray(atm0.t_lay + dT[None, :]); atm0.t_lev = np.ascontiguousarray(atm0.t_lev + dT[None, :]); atm0.t_sfc = atm0.t_sfc + dT
+    atm0.emis_sfc = np.ascontiguousarray(atm0.emis_sfc * rng.uniform(0.9, 1.0, ncol)[:, None])      # column-dependent surface properties
+    atm0.mu0 = np.ascontiguousarray(rng.uniform(0.2, 1.0, ncol))
+    atm = pipeline.upload_atmosphere(be, atm0)
+    cast = lambda lut: be.upload_lut(lut)
+    luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
+    out = {}
+    for mode in ("0", "1", "auto"):
+        sv = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=True, cloud_luts=luts, sort_columns=mode)
+        out[mode] = (sv.sort_columns, be.to_numpy(sv.step()).copy(), be.to_numpy(sv.step()).copy())
+    assert out["0"][0] is False and out["1"][0] is True and out["auto"][0] is True
+    assert np.array_equal(out["1"][1], out["1"][2]), "a second step must reproduce the first"
+    for i, name in enumerate(("lw_up", "lw_dn", "lw_net", "sw_up", "sw_dn", "sw_dir", "sw_net")):
+        e = cases.rel_err(out["1"][1][i], out["0"][1][i])
+        assert e <= (1e-9 if name.startswith("sw") else 1e-11), (name, e)
+    assert np.array_equal(out["auto"][1], out["1"][1])
+
+
 @pytest.mark.parametrize("kind", ["lw", "sw"])
 @pytest.mark.parametrize("flow", ["per-gpoint", "product"])
 def test_c3_allsky_256_gpoints_fp64_matches_oracle(kind, flow, hip_f64, oracle_f64):
