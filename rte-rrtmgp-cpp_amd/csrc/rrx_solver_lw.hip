@@ -145,7 +145,7 @@ lw_noscat_scan_kernel(
             // a padding layer (level slot beyond the surface) is made transparent through its optical depth: tau = 0 gives
             // trans = 1 and fact = 0 (series branch) exactly, hence zero sources -- one select instead of three
             const F tau_loc = (valid ? tv.v[v] : F(0.)) * D.v[v];
-            const F trans = exp(-tau_loc);
+            const F trans = exp_neg(-tau_loc);
             const F fact = tau_loc > tau_thres ?
                 (F(1.) - trans) * fast_rcp(tau_loc) - trans :
                 tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));

@@ -248,7 +248,7 @@ def test_sw_solver_without_g_equals_zero_g(dt, hip_f64, hip_f32):
         for k in ("flux_up", "flux_dn", "flux_dir"):
             if bb and mg == 1:
                 e = cases.rel_err(be.to_numpy(b[k]), be.to_numpy(a[k]), floor=1e-6 if dt == "f64" else 1e-2)
-                assert e <= (1e-12 if dt == "f64" else 1e-5), (k, e)
+                assert e <= (1e-12 if dt == "f64" else 5e-5), (k, e)      # fp32: two algebraically equal forms of the coefficients, 140 layers
             else:
                 assert np.array_equal(be.to_numpy(a[k]), be.to_numpy(b[k])), (k, bb, mg)
 
