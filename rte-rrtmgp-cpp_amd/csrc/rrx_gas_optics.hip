@@ -1187,6 +1187,9 @@ planck_fraction_kernel(
 #define RRX_GW_PAIR 0     // 1: g-points of a chunk go in pairs where the chunk allows it (measured: SW stage 3.81 -> 3.69 ms alone,
                           // but its registers collide with the batched staging, which brings more: 3.81 -> 3.37 ms)
 #endif
+#ifndef RRX_GW_LDSDMA
+#define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
+#endif
 #ifndef RRX_GW_ABL
 #define RRX_GW_ABL 0      // ablation builds (tools/ab_gw.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop
 #endif
@@ -1275,6 +1278,7 @@ gas_window_kernel(
     #pragma clang fp contract(fast)
     typedef F Vec2 __attribute__((ext_vector_type(2)));
     typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
+    (void)sizeof(Vec2u);
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
@@ -1487,6 +1491,52 @@ gas_window_kernel(
             static_assert((GCH*WBOX) % 256 == 0 && GCH*MBOX <= 256 && NCW == 6, "staging phases are written for these box sizes");
             constexpr int KMAJ = GCH*WBOX/256;
             const int nmaj = ng*WBOX, nmin = ng*MBOX;
+            // (the DMA moves 16 B per lane: fp64 pairs; the fp32 build keeps the register path)
+            constexpr bool DMA = RRX_GW_LDSDMA && sizeof(F) == 8;
+            if constexpr (DMA)
+            {
+            // LDS-DMA staging (round 3): every pair-node goes from the table straight into its LDS slot (`global_load_lds_dwordx4`:
+            // per-lane source address, destination = a wave-uniform base + 16 B x lane -- the boxes are laid out linearly in the
+            // thread index for exactly that). No staging registers, so all loads of a chunk's boxes are in flight together in
+            // every form (the fractions form used to take its two major-type boxes one pair of loads at a time), and no LDS store
+            // instructions. Slots beyond a partial last chunk are filled from the chunk's last g-point (always whole wavefronts: the
+            // instruction takes its LDS base from the first active lane).
+            auto glds = [](const F* __restrict__ src, Vec2* dst)
+            {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            };
+            (void)nmaj; (void)nmin; (void)KMAJ;
+            #pragma unroll
+            for (int k=0; k<KMAJ; ++k)
+            {
+                const int q = tid + 256*k;
+                const int gi = min(q / WBOX, ng-1), r = q % WBOX;
+                const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
+                const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
+                const size_t off = size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn;
+                glds(kmajor + off, Wmaj + q);
+                if constexpr (PF) glds(pa.pfracin + off, Wpf + q);
+            }
+            if (tid < GCH*MBOX)                                             // wavefronts 0-2 in full
+            {
+                const int gi_m = min(tid / MBOX, ng-1), r_m = tid % MBOX;   // this thread's node of a minor / Rayleigh box
+                const int it_m = min(jt_lo - 1 + r_m % NTW, ntemp-2), ie_m = min(max(je_lo - 1 + r_m / NTW, 0), neta-1);
+                if constexpr (MODE == 1)
+                    glds(krayl + size_t(itr)*tn*ngpt + size_t(c0 + gi_m)*tn + it_m + ie_m*ntemp, Wray + tid);
+                #pragma unroll
+                for (int i=0; i<NCW; ++i)
+                    if (i < n)
+                    {
+                        const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                        const int kg = min(max(c0 + gi_m, lo), hi-1);       // clamped: always a valid table row
+                        glds(kmin + size_t(kg + koff)*tn + it_m + ie_m*ntemp, Wmin + i*GCH*MBOX + tid);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the DMA writes have landed in LDS (the barrier below publishes them)
+            }
+            else
+            {
             auto stage_major = [&](const F* __restrict__ table, Vec2* __restrict__ W)
             {
                 Vec2 v[KMAJ];
@@ -1550,6 +1600,7 @@ gas_window_kernel(
                     #pragma unroll
                     for (int i=3; i<NCW; ++i) if (i < n) Wmin[(i*GCH + gi_m)*MBOX + r_m] = v[i-3];
                 }
+            }
             }
         }
         // per-cell scalings of this chunk's contributors (registers; independent of the staging above)
