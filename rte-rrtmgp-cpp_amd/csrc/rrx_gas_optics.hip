@@ -1184,8 +1184,9 @@ planck_fraction_kernel(
 // PF: the Planck fractions ride along (planck_frac has kmajor's layout: same box, same corner weights) together with the band
 // Planck functions and the surface terms -- the whole "Planck-lite" output of planck_fraction_kernel.
 #ifndef RRX_GW_PAIR
-#define RRX_GW_PAIR 0     // 1: g-points of a chunk go in pairs where the chunk allows it (measured: SW stage 3.81 -> 3.69 ms alone,
-                          // but its registers collide with the batched staging, which brings more: 3.81 -> 3.37 ms)
+#define RRX_GW_PAIR 1     // 1: g-points of a chunk go in pairs where the chunk allows it. Round 2: SW stage 3.81 -> 3.69 ms alone, but its
+                          // registers collided with the batched register staging (3.81 -> 3.37 ms), so it was off. Round 3: with the boxes
+                          // staged by LDS-DMA the registers are free: SW stage 2.50 -> 2.40 ms (same box), on.
 #endif
 #ifndef RRX_GW_LDSDMA
 #define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
@@ -1771,7 +1772,10 @@ gas_window_kernel(
         bool chunk_full = true;
         #pragma unroll
         for (int i=0; i<NCW; ++i) if (i < n && !(slo[i] <= c0 && shi[i] >= gend)) chunk_full = false;
-        constexpr int PAIR = (RRX_GW_PAIR && !(PF && sizeof(F) == 8)) ? 2 : 1;    // the fractions form has no registers to spare in fp64
+#ifndef RRX_GW_PAIR_PF
+#define RRX_GW_PAIR_PF 0
+#endif
+        constexpr int PAIR = (RRX_GW_PAIR && (RRX_GW_PAIR_PF || !(PF && sizeof(F) == 8))) ? 2 : 1;    // the fractions form has no registers to spare in fp64
         if (RRX_GW_ABL != 3)
         for (int gi=0; gi<ng; )
         {
