@@ -90,7 +90,7 @@ interpolation_kernel(
             const F eta = (cmix > F(2.)*tiny) ? cg1 / cmix : F(0.5);
             const F loceta = eta * F(neta-1);
             jeta[itemp + 2*cell] = min(int(loceta)+1, neta-1);
-            const F feta = fmod(loceta, F(1.));
+            const F feta = loceta - trunc(loceta);          // = fmod(loceta, 1) exactly (loceta >= 0), without fmod's division loop
             const F ftemp_term = F(1-itemp) + F(2*itemp-1)*ftemp;
 
             const F f0 = (F(1.)-feta) * ftemp_term;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void flavor_state(const InterpArgs<F>& ia, const Cell
     const F eta = (cmix > F(2.)*Lim<F>::tiny()) ? cg1 / cmix : F(0.5);
     const F loceta = eta * F(neta-1);
     je = min(int(loceta)+1, neta-1);
-    const F feta = fmod(loceta, F(1.));
+    const F feta = loceta - trunc(loceta);                  // = fmod(loceta, 1) exactly (loceta >= 0), without fmod's division loop
     const F ftemp_term = F(1-itemp) + F(2*itemp-1)*c.ftemp;
     const F f0 = (F(1.)-feta) * ftemp_term;
     const F f1 = feta * ftemp_term;
@@ -1225,6 +1225,15 @@ inline dim3 gas_window_grid(const int geom, const int ncol, const int nlay)
 // RRX_GW_STATS=1 (read at every launch, so a host program can switch it on for one solve): after a windowed launch, wait for it,
 // print how many workgroups were handed back to the gather kernel and why, and add them to the calling thread's totals
 // (rrx_gas_window_stats). Diagnostic only: it synchronises the stream.
+#ifndef RRX_GW_TIMING
+#define RRX_GW_TIMING 0   // diagnostic build (tools/gw_timing.sh): wavefront 0 of every workgroup adds the clocks it spends per phase to g_gw_clk, printed with RRX_GW_STATS
+#endif
+#if RRX_GW_TIMING
+__device__ unsigned long long g_gw_clk[8];
+#define RRX_GW_T(k) { const unsigned long long t_ = __builtin_readcyclecounter(); gw_acc[k] += t_ - gw_t; gw_t = t_; }
+#else
+#define RRX_GW_T(k)
+#endif
 thread_local long long g_gw_handed = 0, g_gw_total = 0;
 inline void gas_window_stats(const char* what, const int* todo, const int nblk, hipStream_t st)
 {
@@ -1234,6 +1243,15 @@ inline void gas_window_stats(const char* what, const int* todo, const int nblk, 
     g_gw_handed += h[8]; g_gw_total += nblk;
     std::fprintf(stderr, "[gas window %s] %d of %d workgroups handed back: temperature %d, pressure %d, regimes %d, chunk form %d, eta %d\n",
                  what, h[8], nblk, h[0], h[1], h[2], h[3], h[4]);
+#if RRX_GW_TIMING
+    unsigned long long clk[8], zero[8] = {0};
+    if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_gw_clk), sizeof(clk)) == hipSuccess)
+    {
+        std::fprintf(stderr, "[gas window %s] clocks per workgroup (wavefront 0): set-up %.0f, chunk prologue %.0f, staging %.0f, dma wait %.0f, barriers %.0f, g-point loop %.0f, tail %.0f\n",
+                     what, double(clk[0])/nblk, double(clk[1])/nblk, double(clk[2])/nblk, double(clk[3])/nblk, double(clk[4])/nblk, double(clk[5])/nblk, double(clk[6])/nblk);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gw_clk), zero, sizeof(zero));
+    }
+#endif
 }
 
 template<typename F> struct PlanckArgs
@@ -1242,65 +1260,42 @@ template<typename F> struct PlanckArgs
     F totplnk_delta; const F* totplnk; F* pfrac; F* blay; F* blev; F* sfc_src; F* sfc_src_jac;
 };
 
-template<typename F>
-size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int mode, const bool pf)
+// ints of the windowed kernel's index tables (a multiple of four: they travel as 16-byte words)
+inline __host__ __device__ int gas_window_table_ints(const int ngpt, const int nmax)
 {
     const int nchunk = (ngpt + GCH - 1) / GCH;
-    const size_t ints = size_t(3)*ngpt + size_t(2)*nchunk*(1 + ITEM*NCW) + size_t(2)*MM*nmax + 2*nchunk + 16;
-    const size_t pairs = size_t(GCH)*WBOX*(pf ? 2 : 1) + size_t(NCW)*GCH*MBOX + (mode == 1 ? size_t(GCH)*MBOX : 0);
-    return ((ints*sizeof(int) + 15) & ~size_t(15)) + pairs*2*sizeof(F);
+    return (2*ngpt + 2*nchunk*(1 + ITEM*NCW) + 2*MM*nmax + 2*nchunk + 3) & ~3;
 }
 
-#ifndef RRX_GW_MINW
-#define RRX_GW_MINW 3
-#endif
-template<typename F, int MODE, bool PF, bool CLD = false>
-__global__ void __launch_bounds__(256, RRX_GW_MINW)
-gas_window_kernel(
-        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
-        const int nminorlower, const int nminorupper, const int idx_h2o,
+// Index tables of the windowed kernel -- g-point flavors, the contributors' metadata, per-chunk contributor lists and the chunk
+// usability flags -- depend on the k-distribution alone. One small workgroup builds them per launch; the 9 000 workgroups of the
+// windowed kernel copy 9 KB instead of each walking the contributor arrays (set-up 0.40 -> 0.30 of 3.5 ms at C4).
+__global__ void __launch_bounds__(256)
+gas_window_tables_kernel(
+        const int ngpt, const int nminorlower, const int nminorupper,
         const int* __restrict__ gpoint_flavor,
-        const F* __restrict__ kmajor, const F* __restrict__ kminor_lower, const F* __restrict__ kminor_upper,
         const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
         const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
         const Bool* __restrict__ scale_by_complement_lower, const Bool* __restrict__ scale_by_complement_upper,
         const int* __restrict__ idx_minor_lower, const int* __restrict__ idx_minor_upper,
         const int* __restrict__ idx_minor_scaling_lower, const int* __restrict__ idx_minor_scaling_upper,
         const int* __restrict__ kminor_start_lower, const int* __restrict__ kminor_start_upper,
-        const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
-        const F* __restrict__ krayl, const InterpArgs<F> ia,
-        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const PlanckArgs<F> pa,
-        int* __restrict__ todo, const int geom)
+        int* __restrict__ tbl)
 {
-    // The product chain's kernel: multiply-adds of the node sums are contracted into FMAs here and the single-scattering albedo
-    // uses a Newton reciprocal (one rounding fewer per term: 1e-15 relative from the gather / reference-shaped kernels, which
-    // stay bit-exact against the goldens; tests hold this kernel to 1e-12). The interpolation state (cell_state, flavor_state:
-    // integer indices depend on it) and the by-band cloud combination are separate functions and keep their rounding.
-    #pragma clang fp contract(fast)
-    typedef F Vec2 __attribute__((ext_vector_type(2)));
-    typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
-    (void)sizeof(Vec2u);
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
     constexpr int LCAP = 1 + ITEM*NCW;
     int* gflav = lds_int;                                   // [2][ngpt]
-    int* gchg = lds_int + 2*ngpt;                           // [ngpt]
-    int* lists = lds_int + 3*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
+    int* lists = lds_int + 2*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
     int* mmeta = lists + 2*nchunk*LCAP;                     // [2][nmax][MM]
     int* cuni = mmeta + 2*MM*nmax;                          // [2][nchunk]: chunk usable by the windowed path (per regime)
-    int* red = cuni + 2*nchunk;                             // [16] workgroup reductions
-    const size_t int_bytes = ((size_t(3)*ngpt + size_t(2)*nchunk*LCAP + size_t(2)*MM*nmax + 2*nchunk + 16)*sizeof(int) + 15) & ~size_t(15);
-    Vec2* Wmaj = reinterpret_cast<Vec2*>(reinterpret_cast<char*>(lds_int) + int_bytes);     // [GCH][WBOX]
-    Vec2* Wpf  = Wmaj + GCH*WBOX;                                                           // [GCH][WBOX] (PF)
-    Vec2* Wmin = Wpf + (PF ? GCH*WBOX : 0);                                                 // [NCW][GCH][MBOX]
-    Vec2* Wray = Wmin + NCW*GCH*MBOX;                                                       // [GCH][MBOX] (MODE 1)
-
-    const int tid = threadIdx.y*64 + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int ntab = gas_window_table_ints(ngpt, nmax);
+    for (int w = tid; w < ntab; w += 256) lds_int[w] = 0;
+    __syncthreads();
     {
         for (int w = tid; w < 2*ngpt; w += 256) gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
-        for (int w = tid; w < ngpt; w += 256)
-            gchg[w] = (w > 0 && (gpoint_flavor[2*w] != gpoint_flavor[2*w-2] || gpoint_flavor[2*w+1] != gpoint_flavor[2*w-1])) ? 1 : 0;
         for (int w = tid; w < nminorlower; w += 256)
         {
             int* m = mmeta + MM*w;
@@ -1315,7 +1310,6 @@ gas_window_kernel(
             m[2] = idx_minor_scaling_upper[w]; m[3] = scale_by_complement_upper[w] ? 1 : 0;
             m[4] = minor_limits_gpt_upper[2*w]; m[5] = minor_limits_gpt_upper[2*w+1]; m[6] = kminor_start_upper[w];
         }
-        if (tid < 16) red[tid] = (tid >= 6) ? 0 : ((tid & 1) ? -2147483647 : 2147483647);   // 0..5: running min / max pairs; 6, 8: presence masks
     }
     __syncthreads();
     // per-chunk contributor lists (ascending index = the reference's summation order) and the usability flag of the chunk:
@@ -1349,6 +1343,75 @@ gas_window_kernel(
         cuni[w] = (ok && cnt <= NCW) ? 1 : 0;
     }
 
+    __syncthreads();
+    for (int w = tid; w < ntab; w += 256) tbl[w] = lds_int[w];
+}
+
+template<typename F>
+size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int mode, const bool pf)
+{
+    const size_t ints = size_t(gas_window_table_ints(ngpt, nmax)) + 16;
+    const size_t pairs = size_t(GCH)*WBOX*(pf ? 2 : 1) + size_t(NCW)*GCH*MBOX + (mode == 1 ? size_t(GCH)*MBOX : 0);
+    return ((ints*sizeof(int) + 15) & ~size_t(15)) + pairs*2*sizeof(F);
+}
+
+#ifndef RRX_GW_MINW
+#define RRX_GW_MINW 3
+#endif
+template<typename F, int MODE, bool PF, bool CLD = false>
+__global__ void __launch_bounds__(256, RRX_GW_MINW)
+gas_window_kernel(
+        const int ncol, const int nlay, const int ngpt, const int neta, const int npres, const int ntemp,
+        const int nminorlower, const int nminorupper, const int idx_h2o,
+        const int* __restrict__ gpoint_flavor,
+        const F* __restrict__ kmajor, const F* __restrict__ kminor_lower, const F* __restrict__ kminor_upper,
+        const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
+        const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
+        const Bool* __restrict__ scale_by_complement_lower, const Bool* __restrict__ scale_by_complement_upper,
+        const int* __restrict__ idx_minor_lower, const int* __restrict__ idx_minor_upper,
+        const int* __restrict__ idx_minor_scaling_lower, const int* __restrict__ idx_minor_scaling_upper,
+        const int* __restrict__ kminor_start_lower, const int* __restrict__ kminor_start_upper,
+        const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
+        const F* __restrict__ krayl, const InterpArgs<F> ia,
+        F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const PlanckArgs<F> pa,
+        int* __restrict__ todo, const int geom, const int* __restrict__ tbl)
+{
+    // The product chain's kernel: multiply-adds of the node sums are contracted into FMAs here and the single-scattering albedo
+    // uses a Newton reciprocal (one rounding fewer per term: 1e-15 relative from the gather / reference-shaped kernels, which
+    // stay bit-exact against the goldens; tests hold this kernel to 1e-12). The interpolation state (cell_state, flavor_state:
+    // integer indices depend on it) and the by-band cloud combination are separate functions and keep their rounding.
+    #pragma clang fp contract(fast)
+    typedef F Vec2 __attribute__((ext_vector_type(2)));
+    typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
+    (void)sizeof(Vec2u);
+    extern __shared__ int lds_int[];
+    const int nchunk = (ngpt + GCH - 1) / GCH;
+    const int nmax = max(nminorlower, nminorupper);
+    constexpr int LCAP = 1 + ITEM*NCW;
+    int* gflav = lds_int;                                   // [2][ngpt]
+    int* lists = lds_int + 2*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
+    int* mmeta = lists + 2*nchunk*LCAP;                     // [2][nmax][MM]
+    int* cuni = mmeta + 2*MM*nmax;                          // [2][nchunk]: chunk usable by the windowed path (per regime)
+    int* red = lds_int + gas_window_table_ints(ngpt, nmax);  // [16] workgroup reductions (behind the copied tables)
+    const size_t int_bytes = ((size_t(gas_window_table_ints(ngpt, nmax)) + 16)*sizeof(int) + 15) & ~size_t(15);
+    Vec2* Wmaj = reinterpret_cast<Vec2*>(reinterpret_cast<char*>(lds_int) + int_bytes);     // [GCH][WBOX]
+    Vec2* Wpf  = Wmaj + GCH*WBOX;                                                           // [GCH][WBOX] (PF)
+    Vec2* Wmin = Wpf + (PF ? GCH*WBOX : 0);                                                 // [NCW][GCH][MBOX]
+    Vec2* Wray = Wmin + NCW*GCH*MBOX;                                                       // [GCH][MBOX] (MODE 1)
+
+    const int tid = threadIdx.y*64 + threadIdx.x;
+#if RRX_GW_TIMING
+    unsigned long long gw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gw_t = __builtin_readcyclecounter();
+#endif
+    // the index tables depend on the k-distribution alone: gas_window_tables_kernel built them once for this launch
+    {
+        const int n4 = gas_window_table_ints(ngpt, nmax) / 4;
+        const int4* __restrict__ src = reinterpret_cast<const int4*>(tbl);
+        int4* dst = reinterpret_cast<int4*>(lds_int);
+        for (int w = tid; w < n4; w += 256) dst[w] = src[w];
+        if (tid < 16) red[tid] = (tid >= 6) ? 0 : ((tid & 1) ? -2147483647 : 2147483647);   // 0..5: running min / max pairs; 6, 8: presence masks
+    }
+
     // geom 0: the workgroup's four waves are four consecutive layers of 64 columns; geom 1: four 64-column stretches of ONE layer
     // (gas_window_geometry: no workgroup straddles the tropopause or an eta jump between layers then)
     const int icol_raw = geom ? (blockIdx.x*4 + threadIdx.y)*64 + threadIdx.x : blockIdx.x*64 + threadIdx.x;
@@ -1363,6 +1426,7 @@ gas_window_kernel(
     const int jt = cs.jt, jp = cs.jp_raw + itr;
 
     // ---- box in temperature and pressure, one regime per workgroup
+    __syncthreads();                                  // the tables and the reduction slots are in place
     atomicMin(&red[0], jt); atomicMax(&red[1], jt); atomicMin(&red[2], jp); atomicMax(&red[3], jp);
     atomicMin(&red[4], itr); atomicMax(&red[5], itr);
     __syncthreads();
@@ -1445,6 +1509,7 @@ gas_window_kernel(
     int red_slot = 6;                                                  // alternating pairs of reduction slots: 6/7, 8/9
 
     if (RRX_GW_ABL == 1) return;
+    RRX_GW_T(0)
     for (int c=c_lo; c<c_hi; ++c)
     {
         const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
@@ -1482,7 +1547,9 @@ gas_window_kernel(
         const int n = rfl(lists[(itr_s*nchunk + c)*LCAP]);
         const int* items = lists + (itr_s*nchunk + c)*LCAP + 1;
 
+        RRX_GW_T(1)
         __syncthreads();                        // the previous chunk's readers are done with the windows
+        RRX_GW_T(4)
         // ---- stage the boxes: pairs (T, T+1) are adjacent words of the tables (temperature is their fastest dimension)
         if (RRX_GW_ABL != 2)
         {
@@ -1534,7 +1601,9 @@ gas_window_kernel(
                         glds(kmin + size_t(kg + koff)*tn + it_m + ie_m*ntemp, Wmin + i*GCH*MBOX + tid);
                     }
             }
+            RRX_GW_T(2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the DMA writes have landed in LDS (the barrier below publishes them)
+            RRX_GW_T(3)
             }
             else
             {
@@ -1612,13 +1681,45 @@ gas_window_kernel(
             sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
             if (i < n) { sc[i] = minor_scaling(rfl(items[ITEM*i])); slo[i] = rfl(items[ITEM*i+1]); shi[i] = rfl(items[ITEM*i+2]); }
         }
+        RRX_GW_T(1)
         __syncthreads();
+        RRX_GW_T(4)
 
         // ---- the cell's corners inside the boxes
         const int e0 = je[0] - je_lo, e1 = je[1] - je_lo;               // eta node je-1 sits at box index je - je_lo
         const int m00 = (pi0*NEW + e0)*NTW + ti, m10 = (pi0*NEW + e1)*NTW + ti;      // kmajor: pressure node jp-1, eta node je-1
         const int q0 = e0*NTW + ti, q1 = e1*NTW + ti;                               // kminor / krayl
         const bool wave_same_eta = !__any(je[0] != je[1]);
+
+        // band Planck functions and surface terms of the fractions form, once per band. The band is looked up once per chunk where the
+        // chunk lies in one band (the rule): a per-g-point look-up is a global load the wavefront waits for with `vmcnt(0)`, i.e.
+        // behind every store it has in flight -- round-3 phase clocks: 1 660 clocks per g-point and wavefront with it, against
+        // ~800 for the same loop without.
+        [[maybe_unused]] auto band_update = [&](const int ibnd)
+        {
+            if constexpr (PF)
+            {
+                cur_bnd = ibnd;
+                const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
+                const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                const F bv = interp1d(pa.tlev[idx], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
+                if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                if (is_sfc)
+                {
+                    const F t_sfc = pa.tsfc[icol];
+                    b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                    b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                }
+            }
+        };
+        [[maybe_unused]] bool one_band = false;
+        if constexpr (PF)
+        {
+            const int b0 = rfl(pa.gpoint_bands[c0]) - 1, b1 = rfl(pa.gpoint_bands[gend-1]) - 1;
+            one_band = b0 == b1;
+            if (one_band && b0 != cur_bnd) band_update(b0);
+        }
 
         // ---- the chunk's g-points, one per iteration (measured alternatives, all slower on MI355X: batches of 2-8 g-points
         // with their LDS reads issued together -- the registers cost the third wave per SIMD --, contributor reads preloaded
@@ -1739,21 +1840,10 @@ gas_window_kernel(
                     F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
                     if (!wave_same_eta) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
                     const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
-                    const int ibnd = pa.gpoint_bands[ig] - 1;
-                    if (ibnd != cur_bnd)
+                    if (!one_band)                                  // (a chunk with a band boundary inside: not the rule)
                     {
-                        cur_bnd = ibnd;
-                        const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
-                        const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                        const F bv = interp1d(pa.tlev[idx], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                        if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
-                        if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                        if (is_sfc)
-                        {
-                            const F t_sfc = pa.tsfc[icol];
-                            b_sfc  = interp1d(t_sfc        , ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                            b_sfc2 = interp1d(t_sfc + F(1.), ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                        }
+                        const int ibnd = rfl(pa.gpoint_bands[ig]) - 1;
+                        if (ibnd != cur_bnd) band_update(ibnd);
                     }
                     if (active)
                     {
@@ -1782,7 +1872,13 @@ gas_window_kernel(
             if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, std::false_type{}, gi); gi += 2; }
             else { gstep(std::integral_constant<int,1>{}, std::true_type{}, gi); gi += 1; }
         }
+        RRX_GW_T(5)
     }
+#if RRX_GW_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RRX_GW_T(6)
+    if (tid == 0) for (int k=0; k<7; ++k) atomicAdd(&g_gw_clk[k], gw_acc[k]);
+#endif
     (void)SZ;
 }
 
@@ -1857,6 +1953,12 @@ int gas_optics_lw_fractions_impl(
     {
         todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+        int* tbl = scratch.get<int>(size_t(gas_window_table_ints(ngpt, nmax)));
+        gas_window_tables_kernel<<<1, 256, size_t(gas_window_table_ints(ngpt, nmax))*sizeof(int), st>>>(
+                ngpt, nminorlower, nminorupper, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
+                idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                kminor_start_lower, kminor_start_upper, tbl);
         const PlanckArgs<F> pa{pfracin, tlev, tsfc, sfc_lay, nPlanckTemp, gpoint_bands, totplnk_delta, totplnk, pfrac, blay, blev, sfc_src, sfc_src_jac};
 #define RRX_GW_PF_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
                 kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
@@ -1864,7 +1966,7 @@ int gas_optics_lw_fractions_impl(
                 scale_by_complement_lower, scale_by_complement_upper, \
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                 kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia, \
-                tau, (F*)nullptr, (F*)nullptr, pa, todo, geom
+                tau, (F*)nullptr, (F*)nullptr, pa, todo, geom, tbl
         if (ia.cld_tau != nullptr) gas_window_kernel<F,2,true,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
         else gas_window_kernel<F,2,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
 #undef RRX_GW_PF_ARGS
@@ -1929,13 +2031,19 @@ int tau_absorption_impl(
             const int nz = gas_window_parts(nblk, nchunk);
             int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
+            int* tbl = scratch.get<int>(size_t(gas_window_table_ints(ngpt, nmax)));
+            gas_window_tables_kernel<<<1, 256, size_t(gas_window_table_ints(ngpt, nmax))*sizeof(int), st>>>(
+                    ngpt, nminorlower, nminorupper, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                    minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
+                    idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
+                    kminor_start_lower, kminor_start_upper, tbl);
 #define RRX_GW_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
                     minor_scales_with_density_lower, minor_scales_with_density_upper, \
                     scale_by_complement_lower, scale_by_complement_upper, \
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                     kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g, \
-                    PlanckArgs<F>(), todo, geom
+                    PlanckArgs<F>(), todo, geom, tbl
 #define RRX_TA_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
                     minor_scales_with_density_lower, minor_scales_with_density_upper, \
