@@ -1247,8 +1247,8 @@ inline void gas_window_stats(const char* what, const int* todo, const int nblk, 
     unsigned long long clk[8], zero[8] = {0};
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_gw_clk), sizeof(clk)) == hipSuccess)
     {
-        std::fprintf(stderr, "[gas window %s] clocks per workgroup (wavefront 0): set-up %.0f, chunk prologue %.0f, staging %.0f, dma wait %.0f, barriers %.0f, g-point loop %.0f, tail %.0f\n",
-                     what, double(clk[0])/nblk, double(clk[1])/nblk, double(clk[2])/nblk, double(clk[3])/nblk, double(clk[4])/nblk, double(clk[5])/nblk, double(clk[6])/nblk);
+        std::fprintf(stderr, "[gas window %s] clocks per workgroup (wavefront 0): set-up %.0f, chunk prologue %.0f, staging %.0f, dma wait %.0f, barriers %.0f, g-point loop %.0f, tail %.0f, contributor scalings %.0f\n",
+                     what, double(clk[0])/nblk, double(clk[1])/nblk, double(clk[2])/nblk, double(clk[3])/nblk, double(clk[4])/nblk, double(clk[5])/nblk, double(clk[6])/nblk, double(clk[7])/nblk);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gw_clk), zero, sizeof(zero));
     }
 #endif
@@ -1264,7 +1264,7 @@ template<typename F> struct PlanckArgs
 inline __host__ __device__ int gas_window_table_ints(const int ngpt, const int nmax)
 {
     const int nchunk = (ngpt + GCH - 1) / GCH;
-    return (2*ngpt + 2*nchunk*(1 + ITEM*NCW) + 2*MM*nmax + 2*nchunk + 3) & ~3;
+    return (2*ngpt + 2*nchunk*(1 + ITEM*NCW) + 2*MM*nmax + 4*nchunk + 3) & ~3;
 }
 
 // Index tables of the windowed kernel -- g-point flavors, the contributors' metadata, per-chunk contributor lists and the chunk
@@ -1341,6 +1341,21 @@ gas_window_tables_kernel(
         }
         out[0] = cnt;
         cuni[w] = (ok && cnt <= NCW) ? 1 : 0;
+    }
+    // chunk order per regime: chunks of one flavor next to each other (stable), so that a workgroup evaluates each flavor's
+    // interpolation state once instead of once per band that uses it
+    if (tid < 2)
+    {
+        int* ord = cuni + 2*nchunk + tid*nchunk;
+        int k = 0;
+        for (int c=0; c<nchunk; ++c)
+        {
+            const int fl = gflav[tid*ngpt + c*GCH];
+            bool seen = false;
+            for (int d=0; d<c; ++d) seen = seen || (gflav[tid*ngpt + d*GCH] == fl);
+            if (seen) continue;
+            for (int d=c; d<nchunk; ++d) if (gflav[tid*ngpt + d*GCH] == fl) ord[k++] = d;
+        }
     }
 
     __syncthreads();
@@ -1510,9 +1525,12 @@ gas_window_kernel(
 
     if (RRX_GW_ABL == 1) return;
     RRX_GW_T(0)
-    for (int c=c_lo; c<c_hi; ++c)
+    const int* corder = cuni + 2*nchunk + rfl(itr)*nchunk;             // (one regime per workgroup here)
+    for (int kc=c_lo; kc<c_hi; ++kc)
     {
+        const int c = (gridDim.z == 1) ? rfl(corder[kc]) : kc;          // (parts of the chunk range keep the natural order: the gather kernel redoes a handed-back part by its range)
         const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
+        if constexpr (CLD) cb = 0;                                     // (chunks do not ascend any more)
         const int fl = gflav[itr*ngpt + c0];
         if (fl != cur_flav)                                            // workgroup-uniform
         {
@@ -1681,7 +1699,7 @@ gas_window_kernel(
             sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
             if (i < n) { sc[i] = minor_scaling(rfl(items[ITEM*i])); slo[i] = rfl(items[ITEM*i+1]); shi[i] = rfl(items[ITEM*i+2]); }
         }
-        RRX_GW_T(1)
+        RRX_GW_T(7)
         __syncthreads();
         RRX_GW_T(4)
 
@@ -1720,6 +1738,7 @@ gas_window_kernel(
             one_band = b0 == b1;
             if (one_band && b0 != cur_bnd) band_update(b0);
         }
+        RRX_GW_T(1)
 
         // ---- the chunk's g-points, one per iteration (measured alternatives, all slower on MI355X: batches of 2-8 g-points
         // with their LDS reads issued together -- the registers cost the third wave per SIMD --, contributor reads preloaded
@@ -1877,7 +1896,7 @@ gas_window_kernel(
 #if RRX_GW_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RRX_GW_T(6)
-    if (tid == 0) for (int k=0; k<7; ++k) atomicAdd(&g_gw_clk[k], gw_acc[k]);
+    if (tid == 0) for (int k=0; k<8; ++k) atomicAdd(&g_gw_clk[k], gw_acc[k]);
 #endif
     (void)SZ;
 }
