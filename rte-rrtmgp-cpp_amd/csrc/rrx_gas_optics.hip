@@ -21,8 +21,12 @@ namespace
 #ifndef RRX_GW_NT
 #define RRX_GW_NT 1       // the cell arrays are written once and far exceed the caches: non-temporal stores keep them from evicting the LUTs
 #endif
+#ifndef RRX_GW_ABL
+#define RRX_GW_ABL 0      // ablation builds (tools/ab_extra.sh, tools/gw_timing.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop, 7 = no stores
+#endif
 template<typename F> __device__ __forceinline__ void stream_store(F* p, const F v)
 {
+    if (RRX_GW_ABL == 7) { if (v == F(-12345.678)) *p = v; return; }
 #if RRX_GW_NT
     __builtin_nontemporal_store(v, p);
 #else
@@ -1191,9 +1195,6 @@ planck_fraction_kernel(
 #ifndef RRX_GW_LDSDMA
 #define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
-#ifndef RRX_GW_ABL
-#define RRX_GW_ABL 0      // ablation builds (tools/ab_gw.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop
-#endif
 constexpr int NPW = 4, NEW = 4, NTW = 3;
 constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, planck_frac
 constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
@@ -1483,6 +1484,13 @@ gas_window_kernel(
     const int ti = jt - jt_lo;                                        // pair (jt-1, jt) inside the box
     const int pi0 = jp - jp_lo;                                       // pressure node jp-1 inside the box (box starts at jp_lo-1)
 
+    // a cell's element of g-point slab ig of a (col, lay, gpt) array: uniform 64-bit slab base + the cell's 32-bit byte offset --
+    // the scalar-base form of the store (no 64-bit address arithmetic per lane and store, no address registers)
+    const unsigned idx_b = unsigned(idx)*SZ;
+    auto slab_store = [&](F* __restrict__ arr, const int ig, const F v)
+    {
+        stream_store(reinterpret_cast<F*>(reinterpret_cast<char*>(arr + size_t(ig)*ncl) + idx_b), v);
+    };
     auto minor_scaling = [&](const int imnr) -> F                      // gas_optics_rrtmgp_kernels.cu:505-529
     {
         const int* m = mmeta + MM*(itr*nmax + imnr);
@@ -1504,13 +1512,15 @@ gas_window_kernel(
     };
 
     // Planck-lite extras
-    [[maybe_unused]] F b_sfc = F(0.), b_sfc2 = F(0.);     // (level / surface temperatures are re-read at each band change: once per 16 g-points)
+    [[maybe_unused]] F b_sfc = F(0.), b_sfc2 = F(0.);     // (the surface temperature is re-read at each band change, by the surface layer's lanes)
     [[maybe_unused]] bool is_last = false, is_sfc = false;
     [[maybe_unused]] int cur_bnd = -1;
     [[maybe_unused]] const size_t ncv = size_t(ncol)*(nlay+1);
+    [[maybe_unused]] F t_lev = F(0.);                      // kept for the whole kernel: a band step then has one memory round trip, not two
     if constexpr (PF)
     {
         is_last = ilay == nlay-1; is_sfc = ilay == pa.sfc_lay-1;
+        t_lev = pa.tlev[idx];
     }
 
     int cur_flav = -1, je_lo = 1;
@@ -1587,6 +1597,8 @@ gas_window_kernel(
             // every form (the fractions form used to take its two major-type boxes one pair of loads at a time), and no LDS store
             // instructions. Slots beyond a partial last chunk are filled from the chunk's last g-point (always whole wavefronts: the
             // instruction takes its LDS base from the first active lane).
+            const F* kmin_u = rfl(itr) == 0 ? kminor_lower : kminor_upper;      // (uniform: one regime per workgroup)
+            auto byte_off = [](const F* __restrict__ base, const unsigned boff) { return reinterpret_cast<const F*>(reinterpret_cast<const char*>(base) + boff); };
             auto glds = [](const F* __restrict__ src, Vec2* dst)
             {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1600,23 +1612,23 @@ gas_window_kernel(
                 const int gi = min(q / WBOX, ng-1), r = q % WBOX;
                 const int p = r / (NEW*NTW), e = (r / NTW) % NEW, t = r % NTW;
                 const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p, 0), npres);
-                const size_t off = size_t(c0 + gi)*s_gpt + size_t(it_) + size_t(ie)*ntemp + size_t(ip)*tn;
-                glds(kmajor + off, Wmaj + q);
-                if constexpr (PF) glds(pa.pfracin + off, Wpf + q);
+                const unsigned off = (unsigned(c0 + gi)*unsigned(s_gpt) + unsigned(it_ + ie*ntemp + ip*tn))*SZ;     // bytes (the tables are far below 4 GB)
+                glds(byte_off(kmajor, off), Wmaj + q);
+                if constexpr (PF) glds(byte_off(pa.pfracin, off), Wpf + q);
             }
             if (tid < GCH*MBOX)                                             // wavefronts 0-2 in full
             {
                 const int gi_m = min(tid / MBOX, ng-1), r_m = tid % MBOX;   // this thread's node of a minor / Rayleigh box
                 const int it_m = min(jt_lo - 1 + r_m % NTW, ntemp-2), ie_m = min(max(je_lo - 1 + r_m / NTW, 0), neta-1);
                 if constexpr (MODE == 1)
-                    glds(krayl + size_t(itr)*tn*ngpt + size_t(c0 + gi_m)*tn + it_m + ie_m*ntemp, Wray + tid);
+                    glds(byte_off(krayl + size_t(rfl(itr))*tn*ngpt, unsigned((c0 + gi_m)*tn + it_m + ie_m*ntemp)*SZ), Wray + tid);
                 #pragma unroll
                 for (int i=0; i<NCW; ++i)
                     if (i < n)
                     {
                         const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
                         const int kg = min(max(c0 + gi_m, lo), hi-1);       // clamped: always a valid table row
-                        glds(kmin + size_t(kg + koff)*tn + it_m + ie_m*ntemp, Wmin + i*GCH*MBOX + tid);
+                        glds(byte_off(kmin_u, unsigned((kg + koff)*tn + it_m + ie_m*ntemp)*SZ), Wmin + i*GCH*MBOX + tid);
                     }
             }
             RRX_GW_T(2)
@@ -1720,7 +1732,7 @@ gas_window_kernel(
                 cur_bnd = ibnd;
                 const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
                 const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                const F bv = interp1d(pa.tlev[idx], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                const F bv = interp1d(t_lev, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
                 if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
                 if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
                 if (is_sfc)
@@ -1817,7 +1829,6 @@ gas_window_kernel(
             for (int u=0; u<U; ++u)
             {
                 const int gi = gi0 + u, ig = c0 + gi;
-                const size_t o = idx + size_t(ig)*ncl;
                 if constexpr (CLD)
                 {
                     // the cell's by-band values are read once per band (16 g-points), not per g-point
@@ -1832,8 +1843,8 @@ gas_window_kernel(
                 }
                 if constexpr (MODE == 2)
                 {
-                    if constexpr (CLD) { if (active) stream_store(tau + o, t[u] + c_tau); }
-                    else if (active) stream_store(tau + o, t[u]);
+                    if constexpr (CLD) { if (active) slab_store(tau, ig, t[u] + c_tau); }
+                    else if (active) slab_store(tau, ig, t[u]);
                 }
                 else
                 {
@@ -1843,13 +1854,13 @@ gas_window_kernel(
                     {
                         F gg = F(0.);
                         add_by_band_2str(tt, ww, gg, c_tau, c_ssa, c_g);
-                        if (active) { stream_store(tau + o, tt); stream_store(ssa + o, ww); stream_store(g + o, gg); }
+                        if (active) { slab_store(tau, ig, tt); slab_store(ssa, ig, ww); slab_store(g, ig, gg); }
                     }
                     else if (active)
                     {
-                        stream_store(tau + o, tt);
-                        stream_store(ssa + o, ww);
-                        if (g != nullptr) stream_store(g + o, F(0.));
+                        slab_store(tau, ig, tt);
+                        slab_store(ssa, ig, ww);
+                        if (g != nullptr) slab_store(g, ig, F(0.));
                     }
                 }
                 if constexpr (PF)
@@ -1866,7 +1877,7 @@ gas_window_kernel(
                     }
                     if (active)
                     {
-                        stream_store(pa.pfrac + o, pfrac);
+                        slab_store(pa.pfrac, ig, pfrac);
                         if (is_sfc)
                         {
                             pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
