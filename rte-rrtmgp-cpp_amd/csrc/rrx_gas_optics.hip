@@ -1195,6 +1195,9 @@ planck_fraction_kernel(
 #ifndef RRX_GW_LDSDMA
 #define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
+#ifndef RRX_GW_SPARSE
+#define RRX_GW_SPARSE 1   // only the nodes the workgroup's cells reach are staged (their extent in pressure, eta and temperature), through registers
+#endif
 constexpr int NPW = 4, NEW = 4, NTW = 3;
 constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, planck_frac
 constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
@@ -1524,6 +1527,7 @@ gas_window_kernel(
     }
 
     int cur_flav = -1, je_lo = 1;
+    [[maybe_unused]] int ne_x = NEW;                                   // eta nodes of the current flavor's box that are in use
     [[maybe_unused]] int cb = 0, cb_have = -1;   // CLD: band (0-based) of the g-point being stored (g-points ascend over the chunk loop)
     [[maybe_unused]] F c_tau = F(0.), c_ssa = F(0.), c_g = F(0.);
     F fm[8], cm[2], fn[4]; int je[2] = {1, 1};
@@ -1568,6 +1572,7 @@ gas_window_kernel(
             red_slot = (red_slot == 6) ? 8 : 6;
             if (tid == 0) red[red_slot] = 0;                            // visible after the next barrier
             if (je_hi - je_lo + 2 > NEW) { hand_back(4); return; }
+            ne_x = je_hi - je_lo + 2;
         }
         // (the regime is the same in every lane here: readfirstlane moves the chunk's list into scalar registers, so that the
         //  contributor conditions of the g-point loop are scalar branches instead of exec-mask sequences)
@@ -1589,7 +1594,70 @@ gas_window_kernel(
             const int nmaj = ng*WBOX, nmin = ng*MBOX;
             // (the DMA moves 16 B per lane: fp64 pairs; the fp32 build keeps the register path)
             constexpr bool DMA = RRX_GW_LDSDMA && sizeof(F) == 8;
-            if constexpr (DMA)
+            // (the fp64 forms without fractions keep the DMA: with the staging registers they spill, and a spill reload at the top of a
+            //  chunk waits behind every store in flight)
+            if constexpr (RRX_GW_SPARSE && (PF || !DMA))
+            {
+                // Sparse staging (round 3): a full box is 4 pressure x 4 eta nodes x 3 temperature pairs per g-point, what the cells of
+                // a workgroup reach is usually 2 x 2 x 1 (one layer of neighbouring columns). Every 16-byte pair pulls its 128-byte line
+                // through the L1, so staging the full boxes moved ~100 KB per chunk and workgroup (phase clocks: ~3 000 clocks per chunk,
+                // 10-12 % of a workgroup's life). Only the nodes in reach are loaded -- into the same places of the same boxes, so the
+                // g-point loop does not change; they go through registers because the places are no longer consecutive.
+                // (x / d for x < 2^16 and small d as a multiplication: exact with m = floor((2^32 - 1) / d) + 1)
+                auto magic = [](const int d) -> unsigned { return 0xFFFFFFFFu / unsigned(d) + 1u; };
+                auto divs = [](const int x, const int d, const unsigned m) -> int { return d == 1 ? x : int(__umulhi(unsigned(x), m)); };
+                const int np_x = rfl(red[3]) - jp_lo + 2, nt_x = rfl(red[1]) - jt_lo + 1;          // pressure nodes, temperature pairs in use
+                const int et = ne_x*nt_x, wb = np_x*et;
+                const unsigned m_wb = magic(wb), m_et = magic(et), m_t = magic(nt_x);
+                const int n_maj = ng*wb, n_min = ng*et;
+                for (int q = tid; q < n_maj; q += 256)
+                {
+                    const int gi = divs(q, wb, m_wb), r = q - gi*wb;
+                    const int p_ = divs(r, et, m_et), r2 = r - p_*et;
+                    const int e = divs(r2, nt_x, m_t), t = r2 - e*nt_x;
+                    const int it_ = min(jt_lo - 1 + t, ntemp-2), ie = min(max(je_lo - 1 + e, 0), neta-1), ip = min(max(jp_lo - 1 + p_, 0), npres);
+                    const unsigned off = (unsigned(c0 + gi)*unsigned(s_gpt) + unsigned(it_ + ie*ntemp + ip*tn))*SZ;
+                    const int slot = gi*WBOX + (p_*NEW + e)*NTW + t;
+                    const Vec2 vm = *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(kmajor) + off);
+                    [[maybe_unused]] Vec2 vp;
+                    if constexpr (PF) vp = *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(pa.pfracin) + off);
+                    Wmaj[slot] = vm;
+                    if constexpr (PF) Wpf[slot] = vp;
+                }
+                if (tid < n_min)
+                {
+                    const int gi_m = divs(tid, et, m_et), r_m = tid - gi_m*et;
+                    const int e = divs(r_m, nt_x, m_t), t = r_m - e*nt_x;
+                    const int it_m = min(jt_lo - 1 + t, ntemp-2), ie_m = min(max(je_lo - 1 + e, 0), neta-1);
+                    const int slot = gi_m*MBOX + e*NTW + t;
+                    const unsigned roff = unsigned(it_m + ie_m*ntemp)*SZ;
+                    const F* kmin_u = rfl(itr) == 0 ? kminor_lower : kminor_upper;
+                    auto minor_node = [&](const int i) -> Vec2
+                    {
+                        const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                        const int kg = min(max(c0 + gi_m, lo), hi-1);                   // clamped: always a valid table row
+                        return *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(kmin_u) + unsigned((kg + koff)*tn)*SZ + roff);
+                    };
+                    Vec2 v[3]; [[maybe_unused]] Vec2 vray;
+                    if constexpr (MODE == 1)
+                        vray = *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(krayl + size_t(rfl(itr))*tn*ngpt) + unsigned((c0 + gi_m)*tn)*SZ + roff);
+                    #pragma unroll
+                    for (int i=0; i<3; ++i) if (i < n) v[i] = minor_node(i);
+                    if constexpr (MODE == 1) Wray[slot] = vray;
+                    #pragma unroll
+                    for (int i=0; i<3; ++i) if (i < n) Wmin[i*GCH*MBOX + slot] = v[i];
+                    if (n > 3)
+                    {
+                        #pragma unroll
+                        for (int i=3; i<NCW; ++i) if (i < n) v[i-3] = minor_node(i);
+                        #pragma unroll
+                        for (int i=3; i<NCW; ++i) if (i < n) Wmin[i*GCH*MBOX + slot] = v[i-3];
+                    }
+                }
+                RRX_GW_T(2)
+                RRX_GW_T(3)
+            }
+            else if constexpr (DMA)
             {
             // LDS-DMA staging (round 3): every pair-node goes from the table straight into its LDS slot (`global_load_lds_dwordx4`:
             // per-lane source address, destination = a wave-uniform base + 16 B x lane -- the boxes are laid out linearly in the
