@@ -293,19 +293,14 @@ tau_absorption_kernel(
     // g-point chunks (gas_window_kernel's grid.z); blocks beyond the count todo[0] have nothing to do.
     // (Spreading each handed-back workgroup over several gather workgroups was measured at C4 with 4 shares: 0.44 -> 0.38 ms for
     //  SW, 0.27 -> 0.31 ms for LW -- the per-workgroup set-up dominates -- so there is one gather workgroup per entry.)
-    int blk_x = blockIdx.x, blk_y = blockIdx.y;
+    // Round 3: the grid is capped (gather_grid) and a workgroup takes entries one after the other (the first by its index, the next
+    // from a counter in the list's header: todo[-1] for this kernel, todo[-2] for planck_fraction_kernel): the usual launch
+    // -- nothing handed back -- starts 2 048 workgroups that leave at once instead of one per windowed workgroup (0.12 -> 0.03 ms
+    // at C4), and a workgroup that does take entries builds its index tables once for all of them.
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
-    int c_lo = 0, c_hi = nchunk;
-    if (todo != nullptr)
-    {
-        if (int(blockIdx.x) >= todo[0]) return;
-        const int entry = todo[1 + blockIdx.x];
-        const int part = entry / todo_nblk, blk = entry % todo_nblk;
-        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
-        const int per = (nchunk + todo_nz - 1) / todo_nz;
-        c_lo = part*per; c_hi = min(nchunk, c_lo + per);
-    }
+    const int n_entries = (todo != nullptr) ? todo[0] : 1;
+    if (todo != nullptr && int(blockIdx.x) >= n_entries) return;
     const int nmax = max(nminorlower, nminorupper);
     int* gflav = lds_int;                                   // [2][ngpt]
     int* gchg = lds_int + 2*ngpt;                           // [ngpt] 1 where the flavor of either regime changes
@@ -338,10 +333,33 @@ tau_absorption_kernel(
     const MinorIndex mi = build_minor_index(lists, nchunk, nmax, gflav, ngpt, mmeta, nminorlower, nminorupper);
     __syncthreads();
 
+    __shared__ int s_next;
+    for (int ientry = (todo != nullptr) ? int(blockIdx.x) : 0; ientry < n_entries; )
+    {
+    // the next entry of this workgroup: taken from a counter (entries differ in cost, a fixed stride left the last workgroups alone)
+    const int ientry_now = ientry;
+    if (todo != nullptr)
+    {
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) s_next = int(gridDim.x) + atomicAdd(const_cast<int*>(todo) - 1, 1);
+        __syncthreads();
+        ientry = s_next;
+    }
+    else ientry = n_entries;
+    int blk_x = blockIdx.x, blk_y = blockIdx.y;
+    int c_lo = 0, c_hi = nchunk;
+    if (todo != nullptr)
+    {
+        const int entry = todo[1 + ientry_now];
+        const int part = entry / todo_nblk, blk = entry % todo_nblk;
+        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+        const int per = (nchunk + todo_nz - 1) / todo_nz;
+        c_lo = part*per; c_hi = min(nchunk, c_lo + per);
+    }
     // (todo_geom 1: the handed-back workgroup was 256 columns of one layer, see gas_window_geometry)
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*blockDim.x + threadIdx.x;
     const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
-    if (icol >= ncol || ilay >= nlay) return;
+    if (icol >= ncol || ilay >= nlay) continue;
 
     const size_t ncl = size_t(ncol)*nlay;
     const size_t idx = icol + size_t(ilay)*ncol;
@@ -705,6 +723,7 @@ tau_absorption_kernel(
         }
     }
     }   // regime passes
+    }   // entries
 }
 
 
@@ -1065,25 +1084,38 @@ planck_fraction_kernel(
         F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1,
         const int todo_nblk = 1, const int todo_nz = 1, const int todo_geom = 0)
 {
-    int blk_x = blockIdx.x, blk_y = blockIdx.y;             // todo: see tau_absorption_kernel
-    int g_lo = 0, g_hi = ngpt;
-    if (todo != nullptr)
-    {
-        if (int(blockIdx.x) >= todo[0]) return;
-        const int entry = todo[1 + blockIdx.x];
-        const int part = entry / todo_nblk, blk = entry % todo_nblk;
-        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
-        const int nchunk = (ngpt + GCH - 1) / GCH, per = (nchunk + todo_nz - 1) / todo_nz;
-        g_lo = min(part*per*GCH, ngpt); g_hi = min((part + 1)*per*GCH, ngpt);
-    }
+    const int n_entries = (todo != nullptr) ? todo[0] : 1;  // todo: see tau_absorption_kernel (capped grid, entries walked with the grid as stride)
+    if (todo != nullptr && int(blockIdx.x) >= n_entries) return;
     extern __shared__ int lds_gflav[];                       // [2][ngpt] flavor (0-based) per regime and g-point
     for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*blockDim.y)
         lds_gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
     __syncthreads();
 
+    __shared__ int s_next;
+    for (int ientry = (todo != nullptr) ? int(blockIdx.x) : 0; ientry < n_entries; )
+    {
+    const int ientry_now = ientry;                           // (next entry from a counter of its own: todo[-2])
+    if (todo != nullptr)
+    {
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) s_next = int(gridDim.x) + atomicAdd(const_cast<int*>(todo) - 2, 1);
+        __syncthreads();
+        ientry = s_next;
+    }
+    else ientry = n_entries;
+    int blk_x = blockIdx.x, blk_y = blockIdx.y;
+    int g_lo = 0, g_hi = ngpt;
+    if (todo != nullptr)
+    {
+        const int entry = todo[1 + ientry_now];
+        const int part = entry / todo_nblk, blk = entry % todo_nblk;
+        blk_x = blk % todo_gx; blk_y = blk / todo_gx;
+        const int nchunk = (ngpt + GCH - 1) / GCH, per = (nchunk + todo_nz - 1) / todo_nz;
+        g_lo = min(part*per*GCH, ngpt); g_hi = min((part + 1)*per*GCH, ngpt);
+    }
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*64 + threadIdx.x;
     const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
-    if (icol >= ncol || ilay >= nlay) return;
+    if (icol >= ncol || ilay >= nlay) continue;
     const size_t ncl = size_t(ncol)*nlay;
     const size_t ncv = size_t(ncol)*(nlay+1);
     const size_t idx = icol + size_t(ilay)*ncol;
@@ -1173,6 +1205,7 @@ planck_fraction_kernel(
         }
         ig = ge;
     }
+    }   // entries
 }
 
 
@@ -1220,6 +1253,12 @@ inline int gas_window_geometry(const int ncol)
 {
     if (const char* e = std::getenv("RRX_GW_GEOM")) return std::atoi(e) ? 1 : 0;
     return ncol >= 192 ? 1 : 0;
+}
+// grid of the gather kernels behind a windowed launch: at most this many workgroups walk over the todo list
+inline dim3 gather_grid(const int entries)
+{
+    static const int cap = std::getenv("RRX_GATHER_GRID") ? std::max(1, std::atoi(std::getenv("RRX_GATHER_GRID"))) : 2048;   // (A/B runs)
+    return dim3(std::min(entries, cap));
 }
 inline dim3 gas_window_grid(const int geom, const int ncol, const int nlay)
 {
@@ -2070,7 +2109,7 @@ int gas_optics_lw_fractions_impl(
 #undef RRX_GW_PF_ARGS
         gas_window_stats("lw + fractions", todo, nblk*nz, st);
     }
-    const dim3 g2 = windowed ? dim3(nblk*nz) : grid;
+    const dim3 g2 = windowed ? gather_grid(nblk*nz) : grid;
 #define RRX_TA_PF_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
             kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
             minor_scales_with_density_lower, minor_scales_with_density_upper, \
@@ -2159,9 +2198,9 @@ int tau_absorption_impl(
             gas_window_stats(MODE == 1 ? "sw" : "lw", todo, nblk*nz, st);
             if constexpr (DIRECT && MODE != 0)
             {
-                if (cld) tau_absorption_kernel<F,MODE,DIRECT,true><<<dim3(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
+                if (cld) tau_absorption_kernel<F,MODE,DIRECT,true><<<gather_grid(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
             }
-            if (!cld) tau_absorption_kernel<F,MODE,DIRECT><<<dim3(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
+            if (!cld) tau_absorption_kernel<F,MODE,DIRECT><<<gather_grid(nblk*nz), block, lds, st>>>(RRX_TA_ARGS);
 #undef RRX_GW_ARGS
 #undef RRX_TA_ARGS
             return check_launch(name);

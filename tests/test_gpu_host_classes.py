@@ -293,3 +293,43 @@ def test_acceptance_script_on_a_stand_in_data_tree(tmp_path, oracle_f64):
     assert len(results) == 9
     for name, diff, thr in results:
         assert diff <= min(thr, 1e-6), (name, diff)
+
+
+def test_driver_solves_differing_columns_in_order_of_surface_pressure(tmp_path, capfd):
+    """--sort-columns (on by default): where neighbouring columns differ by more than a cell of the pressure grid the driver solves
+    them in ascending order of surface pressure -- every per-column input permuted (fields, gases, clouds, aerosols, surface
+    properties), every output written in the order of the input file. Same numbers as --no-sort-columns."""
+    kl, ks = synthetic.make_kdist("lw", **KW), synthetic.make_kdist("sw", **KW)
+    atm = synthetic.make_atmosphere(300, 60, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], clouds=True, aerosols=True, seed=11)
+    rng = np.random.default_rng(3)
+    f = rng.uniform(0.65, 1.35, atm.ncol)
+    atm.p_lay = atm.p_lay * f; atm.p_lev = atm.p_lev * f
+    dt = rng.uniform(-10., 10., atm.ncol)
+    atm.t_lay = atm.t_lay + dt; atm.t_lev = atm.t_lev + dt; atm.t_sfc = atm.t_sfc + dt
+    d = str(tmp_path)
+    synthetic_files.write_case(d, atm, kl, ks, synthetic.make_cloud_lut(KW["nbnd"], "lw"), synthetic.make_cloud_lut(KW["nbnd"], "sw"),
+                               synthetic.make_aerosol_lut(KW["nbnd"]))
+    flags = ("--cloud-optics", "--aerosol-optics", "--output-bnd-fluxes", "--heating-rates")
+    assert run_driver(d, *flags, "--no-sort-columns") == 0
+    _, ref = read_output(d)
+    assert "order of surface pressure" not in capfd.readouterr().out
+    assert run_driver(d, *flags) == 0
+    _, out = read_output(d)
+    assert "order of surface pressure" in capfd.readouterr().out
+    assert np.array_equal(out["p_lev"], ref["p_lev"])                       # the echo of the inputs keeps the file's order
+    # (a column meets other neighbours in the sorted run, so it may take the windowed kernel in one run and the gather kernel in the
+    #  other: 1e-15 apart in the optical depths, which the two-stream solver amplifies -- cases.Checker.sw_tol)
+    n = 0
+    for k in ref:
+        if k.endswith(("_flux_up", "_flux_dn", "_flux_net", "_flux_dn_dir", "_heating_rate")):
+            assert out[k].shape == ref[k].shape, k
+            # (heating rates are differences of neighbouring net fluxes: 1e-13 of a flux is 1e-9 of its divergence)
+            tol = 1e-6 if k.endswith("_heating_rate") else (1e-7 if k.startswith("sw_") else 1e-11)
+            assert cases.rel_err(out[k], ref[k]) <= tol, k
+            n += 1
+    assert n >= 16
+    # alike columns: nothing to sort
+    atm2 = synthetic.make_atmosphere(300, 60, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], seed=11)
+    synthetic_files.write_input(os.path.join(d, "rte_rrtmgp_input.nc"), atm2, KW["nbnd"], KW["nbnd"])
+    assert run_driver(d) == 0
+    assert "order of surface pressure" not in capfd.readouterr().out
