@@ -37,6 +37,10 @@ template<typename F> __device__ __forceinline__ void stream_store(F* p, const F 
 using namespace rrx;
 
 constexpr int GCH = 16;          // g-points per register chunk
+#ifndef RRX_GATHER_SHARES
+#define RRX_GATHER_SHARES 4
+#endif
+constexpr int GSH = RRX_GATHER_SHARES;   // a handed-back workgroup is redone in this many shares of its g-point chunks (few entries: the launch lasts as long as one share)
 
 
 // /root/reference/src_kernels_cuda/gas_optics_rrtmgp_kernels.cu:317-395
@@ -291,15 +295,16 @@ tau_absorption_kernel(
     // todo != null: this launch finishes the workgroups the windowed kernel handed back (gas_window_kernel): a 1-D grid, block b
     // takes over entry todo[1+b] = workgroup + part * todo_nblk of the (todo_gx x . x todo_nz) grid -- a part is a share of the
     // g-point chunks (gas_window_kernel's grid.z); blocks beyond the count todo[0] have nothing to do.
-    // (Spreading each handed-back workgroup over several gather workgroups was measured at C4 with 4 shares: 0.44 -> 0.38 ms for
-    //  SW, 0.27 -> 0.31 ms for LW -- the per-workgroup set-up dominates -- so there is one gather workgroup per entry.)
+    // (Round 2 measured four gather workgroups per entry at C4: 0.44 -> 0.38 ms for SW, 0.27 -> 0.31 ms for LW -- the per-workgroup
+    //  set-up dominated. With the set-up paid once per resident workgroup, below, an entry is redone in GSH shares of its chunks:
+    //  a launch with a handful of entries lasts as long as one share, not as long as one whole workgroup's 256 g-points.)
     // Round 3: the grid is capped (gather_grid) and a workgroup takes entries one after the other (the first by its index, the next
     // from a counter in the list's header: todo[-1] for this kernel, todo[-2] for planck_fraction_kernel): the usual launch
     // -- nothing handed back -- starts 2 048 workgroups that leave at once instead of one per windowed workgroup (0.12 -> 0.03 ms
     // at C4), and a workgroup that does take entries builds its index tables once for all of them.
     extern __shared__ int lds_int[];
     const int nchunk = (ngpt + GCH - 1) / GCH;
-    const int n_entries = (todo != nullptr) ? todo[0] : 1;
+    const int n_entries = (todo != nullptr) ? todo[0]*GSH : 1;          // work items: (entry, share of its chunks)
     if (todo != nullptr && int(blockIdx.x) >= n_entries) return;
     const int nmax = max(nminorlower, nminorupper);
     int* gflav = lds_int;                                   // [2][ngpt]
@@ -350,11 +355,14 @@ tau_absorption_kernel(
     int c_lo = 0, c_hi = nchunk;
     if (todo != nullptr)
     {
-        const int entry = todo[1 + ientry_now];
+        const int entry = todo[1 + ientry_now / GSH], share = ientry_now % GSH;
         const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
         const int per = (nchunk + todo_nz - 1) / todo_nz;
         c_lo = part*per; c_hi = min(nchunk, c_lo + per);
+        const int q = (c_hi - c_lo + GSH - 1) / GSH;
+        c_lo += share*q; c_hi = min(c_hi, c_lo + q);
+        if (c_lo >= c_hi) continue;
     }
     // (todo_geom 1: the handed-back workgroup was 256 columns of one layer, see gas_window_geometry)
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*blockDim.x + threadIdx.x;
@@ -1084,7 +1092,7 @@ planck_fraction_kernel(
         F* __restrict__ sfc_src, F* __restrict__ sfc_src_jac, const int* __restrict__ todo = nullptr, const int todo_gx = 1,
         const int todo_nblk = 1, const int todo_nz = 1, const int todo_geom = 0)
 {
-    const int n_entries = (todo != nullptr) ? todo[0] : 1;  // todo: see tau_absorption_kernel (capped grid, entries walked with the grid as stride)
+    const int n_entries = (todo != nullptr) ? todo[0]*GSH : 1;  // todo: see tau_absorption_kernel (capped grid, work items taken from a counter)
     if (todo != nullptr && int(blockIdx.x) >= n_entries) return;
     extern __shared__ int lds_gflav[];                       // [2][ngpt] flavor (0-based) per regime and g-point
     for (int w = threadIdx.y*64 + threadIdx.x; w < 2*ngpt; w += 64*blockDim.y)
@@ -1107,11 +1115,15 @@ planck_fraction_kernel(
     int g_lo = 0, g_hi = ngpt;
     if (todo != nullptr)
     {
-        const int entry = todo[1 + ientry_now];
+        const int entry = todo[1 + ientry_now / GSH], share = ientry_now % GSH;
         const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
         const int nchunk = (ngpt + GCH - 1) / GCH, per = (nchunk + todo_nz - 1) / todo_nz;
-        g_lo = min(part*per*GCH, ngpt); g_hi = min((part + 1)*per*GCH, ngpt);
+        int c_lo = part*per, c_hi = min(nchunk, c_lo + per);
+        const int q = (c_hi - c_lo + GSH - 1) / GSH;
+        c_lo += share*q; c_hi = min(c_hi, c_lo + q);
+        if (c_lo >= c_hi) continue;
+        g_lo = min(c_lo*GCH, ngpt); g_hi = min(c_hi*GCH, ngpt);
     }
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*64 + threadIdx.x;
     const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
@@ -1255,8 +1267,9 @@ inline int gas_window_geometry(const int ncol)
     return ncol >= 192 ? 1 : 0;
 }
 // grid of the gather kernels behind a windowed launch: at most this many workgroups walk over the todo list
-inline dim3 gather_grid(const int entries)
+inline dim3 gather_grid(const int entries_)
 {
+    const int entries = entries_*GSH;
     static const int cap = std::getenv("RRX_GATHER_GRID") ? std::max(1, std::atoi(std::getenv("RRX_GATHER_GRID"))) : 2048;   // (A/B runs)
     return dim3(std::min(entries, cap));
 }

@@ -250,7 +250,10 @@ void Radiation_solver_longwave::solve_gpu(
         Workspace& ws = *wsp;
         const bool whole = (n_in == n_col);      // a single block needs no gather of the inputs
 
-        Gas_concs_gpu gas_concs_subset(gas_concs, col_s, n_in);
+        // (a single block takes the caller's gases as they are: no device copies of the mixing-ratio fields)
+        std::unique_ptr<Gas_concs_gpu> gas_concs_copy;
+        if (!whole) gas_concs_copy = std::make_unique<Gas_concs_gpu>(gas_concs, col_s, n_in);
+        const Gas_concs_gpu& gas_concs_subset = whole ? gas_concs : *gas_concs_copy;
         auto sub2 = [&](const Array_gpu<Float,2>& a, const int n2) { return whole ? Array_gpu<Float,2>(const_cast<Float*>(a.ptr()), {n_in, n2})
                                                                                   : a.subset({{ {col_s, col_e}, {1, n2} }}); };
         Array_gpu<Float,2> p_lay_s = sub2(p_lay, n_lay), t_lay_s = sub2(t_lay, n_lay);
@@ -394,7 +397,10 @@ void Radiation_solver_shortwave::solve_gpu(
         Workspace& ws = *wsp;
         const bool whole = (n_in == n_col);
 
-        Gas_concs_gpu gas_concs_subset(gas_concs, col_s, n_in);
+        // (a single block takes the caller's gases as they are: no device copies of the mixing-ratio fields)
+        std::unique_ptr<Gas_concs_gpu> gas_concs_copy;
+        if (!whole) gas_concs_copy = std::make_unique<Gas_concs_gpu>(gas_concs, col_s, n_in);
+        const Gas_concs_gpu& gas_concs_subset = whole ? gas_concs : *gas_concs_copy;
         auto sub2 = [&](const Array_gpu<Float,2>& a, const int n2) { return whole ? Array_gpu<Float,2>(const_cast<Float*>(a.ptr()), {n_in, n2})
                                                                                   : a.subset({{ {col_s, col_e}, {1, n2} }}); };
         auto sub1 = [&](const Array_gpu<Float,1>& a) { return whole ? Array_gpu<Float,1>(const_cast<Float*>(a.ptr()), {n_in}) : a.subset({{ {col_s, col_e} }}); };
