@@ -1596,7 +1596,6 @@ gas_window_kernel(
     {
         const int c = (gridDim.z == 1) ? rfl(corder[kc]) : kc;          // (parts of the chunk range keep the natural order: the gather kernel redoes a handed-back part by its range)
         const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
-        if constexpr (CLD) cb = 0;                                     // (chunks do not ascend any more)
         const int fl = gflav[itr*ngpt + c0];
         if (fl != cur_flav)                                            // workgroup-uniform
         {
@@ -1863,6 +1862,27 @@ gas_window_kernel(
                 }
             }
         };
+        // all-sky: the cell's by-band values, read once per chunk where the chunk lies in one band (the rule) -- like the band look-up
+        // of the fractions form, a read inside the loop is waited for behind the stores in flight
+        [[maybe_unused]] auto cld_load = [&](const int ib)
+        {
+            if constexpr (CLD)
+            {
+                cb_have = ib;
+                const size_t b = idx + size_t(ib)*ncl;
+                c_tau = ia.cld_tau[b];
+                if constexpr (MODE != 2) { c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b]; }
+            }
+        };
+        [[maybe_unused]] bool cld_one_band = false;
+        if constexpr (CLD)
+        {
+            int b0 = 0;
+            while (c0 + 1 > rfl(ia.cld_lims[2*b0+1])) ++b0;
+            cb = b0;
+            cld_one_band = gend <= rfl(ia.cld_lims[2*b0+1]);
+            if (cld_one_band && b0 != cb_have) cld_load(b0);
+        }
         [[maybe_unused]] bool one_band = false;
         if constexpr (PF)
         {
@@ -1951,14 +1971,10 @@ gas_window_kernel(
                 const int gi = gi0 + u, ig = c0 + gi;
                 if constexpr (CLD)
                 {
-                    // the cell's by-band values are read once per band (16 g-points), not per g-point
-                    while (ig + 1 > ia.cld_lims[2*cb+1]) ++cb;
-                    if (PF || cb != cb_have)        // (the fractions form has no register to keep the value in: re-read, an L1 hit)
+                    if (!cld_one_band)              // (a chunk with a band boundary inside: not the rule)
                     {
-                        cb_have = cb;
-                        const size_t b = idx + size_t(cb)*ncl;
-                        c_tau = ia.cld_tau[b];
-                        if constexpr (MODE != 2) { c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b]; }
+                        while (ig + 1 > rfl(ia.cld_lims[2*cb+1])) ++cb;
+                        if (cb != cb_have) cld_load(cb);
                     }
                 }
                 if constexpr (MODE == 2)
@@ -2015,7 +2031,12 @@ gas_window_kernel(
 #ifndef RRX_GW_PAIR_PF
 #define RRX_GW_PAIR_PF 0
 #endif
-        constexpr int PAIR = (RRX_GW_PAIR && (RRX_GW_PAIR_PF || !(PF && sizeof(F) == 8))) ? 2 : 1;    // the fractions form has no registers to spare in fp64
+#ifndef RRX_GW_NOPAIR_CLD
+#define RRX_GW_NOPAIR_CLD 1
+#endif
+        // (the fractions form and the all-sky SW form have no registers to spare in fp64: paired they spill, and a spill reload waits
+        //  behind every store in flight)
+        constexpr int PAIR = (RRX_GW_PAIR && (RRX_GW_PAIR_PF || !(PF && sizeof(F) == 8)) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1 && sizeof(F) == 8)) ? 2 : 1;
         if (RRX_GW_ABL != 3)
         for (int gi=0; gi<ng; )
         {
