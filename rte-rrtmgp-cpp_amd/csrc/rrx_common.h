@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -179,6 +180,47 @@ namespace rrx
 
     inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
 
+    // The device's default memory pool keeps what is freed into it (its release threshold is lifted once per thread and device), so
+    // that the stream-ordered scratch of one solve is reused by the next without going back to the driver. Without it the pool
+    // hands everything back at each synchronisation: invisible for the few KB the fused kernels ask for, 250 ms per call for the
+    // per-g-point arrays of the any-nlay solver path (4 096 columns x 272 layers: 585 instead of 25 ms per step).
+    // RRX_POOL_RELEASE_THRESHOLD (bytes) caps what the pool keeps when the GPU is shared with other allocators inside a host model.
+    inline void keep_pool_memory()
+    {
+        static thread_local int configured_device = -1;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev == configured_device) return;
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) return;
+        unsigned long long keep = ~0ull;
+        if (const char* e = std::getenv("RRX_POOL_RELEASE_THRESHOLD")) keep = std::strtoull(e, nullptr, 10);
+        if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) configured_device = dev;
+    }
+
+    // Grow-only device workspace kept per (thread, device, stream) for the large per-g-point temporaries of the any-nlay solver
+    // paths (several GB each at 4 096 columns x 288 layers). Taken from the pool call by call, blocks of these sizes in changing
+    // order made hipMallocAsync go back to the driver every time (rocprofv3 --hip-trace: 90 ms per call on average, 2.1 s at most;
+    // 950 ms per step where the kernels take 25). Work on one stream is ordered, so the block can be handed out again as it is.
+    inline void* cached_workspace(hipStream_t st, const size_t bytes)
+    {
+        struct Slot { int dev; hipStream_t st; void* p; size_t cap; };
+        static thread_local std::vector<Slot> slots;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("workspace allocation failed");
+        Slot* slot = nullptr;
+        for (Slot& s : slots) if (s.dev == dev && s.st == st) slot = &s;
+        if (slot == nullptr) { slots.push_back(Slot{dev, st, nullptr, 0}); slot = &slots.back(); }
+        if (slot->cap < bytes)
+        {
+            if (slot->p != nullptr) (void)hipFreeAsync(slot->p, st);
+            slot->p = nullptr; slot->cap = 0;
+            keep_pool_memory();
+            if (hipMallocAsync(&slot->p, bytes, st) != hipSuccess) throw std::runtime_error("workspace allocation failed");
+            slot->cap = bytes;
+        }
+        return slot->p;
+    }
+
     // Stream-ordered scratch that is returned to the pool on every exit path (a throw after the first allocation must
     // not leak the earlier ones: a transient out-of-memory in a long-running host model would become permanent).
     class StreamScratch
@@ -190,6 +232,7 @@ namespace rrx
             template<typename F> F* get(const size_t n, const bool zero = false)
             {
                 void* p = nullptr;
+                keep_pool_memory();
                 if (hipMallocAsync(&p, n*sizeof(F), st_) != hipSuccess) throw std::runtime_error("workspace allocation failed");
                 ptrs_.push_back(p);
                 if (zero && hipMemsetAsync(p, 0, n*sizeof(F), st_) != hipSuccess) throw std::runtime_error("workspace memset failed");

@@ -437,20 +437,7 @@ int rrx_free(void* ptr) { RRX_HIP_OK(hipFree(ptr), "rrx_free"); return 0; }
 // without going back to the driver -- and without hipFree's device-wide synchronisation.
 int rrx_malloc_async(void** ptr, unsigned long long bytes, void* stream)
 {
-    static thread_local int configured_device = -1;
-    int dev = 0;
-    RRX_HIP_OK(hipGetDevice(&dev), "rrx_malloc_async");
-    if (dev != configured_device)
-    {
-        hipMemPool_t pool;
-        RRX_HIP_OK(hipDeviceGetDefaultMemPool(&pool, dev), "rrx_malloc_async");
-        // freed blocks stay in the pool for the next solve; RRX_POOL_RELEASE_THRESHOLD (bytes) caps what the pool keeps when the
-        // GPU is shared with other allocators inside a host model (default: everything)
-        unsigned long long keep = ~0ull;
-        if (const char* e = std::getenv("RRX_POOL_RELEASE_THRESHOLD")) keep = std::strtoull(e, nullptr, 10);
-        RRX_HIP_OK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep), "rrx_malloc_async");
-        configured_device = dev;
-    }
+    rrx::keep_pool_memory();      // freed blocks stay in the pool for the next solve (rrx_common.h)
     RRX_HIP_OK(hipMallocAsync(ptr, bytes ? bytes : 1, static_cast<hipStream_t>(stream)), "rrx_malloc_async");
     return 0;
 }

@@ -348,8 +348,10 @@ lw_noscat_scan_kernel(
 #ifndef RRX_LW_EV
 #define RRX_LW_EV 2
 #endif
-template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = RRX_LW_EV>
-__global__ void __launch_bounds__(256, 2)
+// NW = wavefronts per workgroup: 4, or 8 with W = 8 for columns of up to 287 layers (round 3: eight waves x four level-lanes x
+// nine layers; one workgroup per CU then, the same two waves per SIMD).
+template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = RRX_LW_EV, int NW = (W > 4 ? W : 4)>
+__global__ void __launch_bounds__(64*NW, NW > 4 ? 1 : 2)
 lw_noscat_bb_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ secants, const F* __restrict__ weights,
@@ -365,9 +367,9 @@ lw_noscat_bb_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & (CL-1), ll = lane / CL;
     const int h = wave % W, w0 = wave - h;
-    const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
-    __shared__ F xch[4*V][4][CL];
-    __shared__ F lds_b[LITE ? (2*K+1)*V : 1][256];       // per-thread columns: B_lay[K], B_lev[K+1] of the current band
+    const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
+    __shared__ F xch[4*V][NW][CL];
+    __shared__ F lds_b[LITE ? (2*K+1)*V : 1][64*NW];     // per-thread columns: B_lay[K], B_lev[K+1] of the current band
     int icol = wave_col0 + cl*V;
     const bool active = icol < ncol;
     if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;
@@ -381,7 +383,7 @@ lw_noscat_bb_kernel(
     // g-point sums of the lane's K levels: in LDS columns for fp64 (the 4*K registers they would take push the kernel past 256
     // VGPRs into scratch; LDS has room for them at the two workgroups per CU the registers allow), in registers for fp32
     constexpr bool LACC = RRX_LW_LACC && sizeof(F) == 8 && V == 1;
-    __shared__ F lds_acc[LACC ? 2*K*V : 1][256];
+    __shared__ F lds_acc[LACC ? 2*K*V : 1][64*NW];
     F acc_up[LACC ? 1 : K][V], acc_dn[LACC ? 1 : K][V];
     #pragma unroll
     for (int j=0; j<K; ++j)
@@ -812,7 +814,8 @@ bool launch_bb2(
         const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
 {
     if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
-    const int groups = ceil_div(ncol, (4/W)*CLT*V);
+    constexpr int NW = (W > 4) ? W : 4;
+    const int groups = ceil_div(ncol, (NW/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
     if (need > ((CLT == 16) ? 9 : 5)) return false;
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
@@ -824,13 +827,13 @@ bool launch_bb2(
     if (nsplit > 1) { out_up = scratch.get<F>(2*nsplit*nlevcol); out_dn = out_up + nsplit*nlevcol; }
     const dim3 grid(groups, nsplit);
 #define RRX_LW_B2(KK) if (need <= KK) { \
-        if (nsplit > 1 && pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        if (nsplit > 1 && pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else if (nsplit > 1) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else if (nsplit > 1) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
         break; }
     do {
@@ -861,8 +864,14 @@ bool lw_fused_broadband(
     // first, for A/B runs). Measured at C4 in the fractions form: 1.77 against 3.26 ms (the four-column lane state spills).
     const bool v2_first = tuning().lw_variant != 14;
     if constexpr (sizeof(F) == 8)
-        return launch_bb2<F,1,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+    {
+        if (launch_bb2<F,1,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        // 144 ... 287 layers: eight wavefronts per column group
+        return launch_bb2<F,1,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                          blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
+    }
     else
     {
         if (ncol % 2 == 0 && v2_first &&
@@ -947,7 +956,7 @@ int lw_solver_noscat_impl(
     if (do_broadband)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
-        F* ws = scratch.get<F>(2*nlevcol*ngpt);
+        F* ws = static_cast<F*>(cached_workspace(st, 2*nlevcol*ngpt*sizeof(F)));      // (first in the stream's cached block)
         up = ws; dn = ws + nlevcol*ngpt;
     }
 
@@ -1040,7 +1049,6 @@ int lw_solver_noscat_fractions_impl(
         RRX_TRY
         if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
-        constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
         const int var = tuning().lw_variant;
         if ((var == 0 || var == 13 || var == 14) &&
             lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
@@ -1049,16 +1057,16 @@ int lw_solver_noscat_fractions_impl(
         } catch (const std::exception& e) { rrx::set_error(std::string("rrx_lw_solver_noscat_fractions: ") + e.what()); return 1; }
     }
     // outside the one-kernel form (few columns, very tall columns, A/B variants): rebuild the sources and take the general entry
+    // (the two source arrays sit behind the room the general entry takes for its per-g-point fluxes in the same cached block)
     F* lay = nullptr; F* lev = nullptr;
     const size_t n_lay = size_t(ncol)*nlay*ngpt, n_lev = size_t(ncol)*(nlay+1)*ngpt;
-    if (hipMallocAsync(reinterpret_cast<void**>(&lay), (n_lay + n_lev)*sizeof(F), st) != hipSuccess)
-    { rrx::set_error("rrx_lw_solver_noscat_fractions: workspace allocation failed"); return 1; }
+    try { lay = static_cast<F*>(cached_workspace(st, (2*n_lev + n_lay + n_lev)*sizeof(F))) + 2*n_lev; }
+    catch (const std::exception& e) { rrx::set_error(std::string("rrx_lw_solver_noscat_fractions: ") + e.what()); return 1; }
     lev = lay + n_lay;
     int rc = planck_sources_from_fractions_impl<F>(ncol, nlay, ngpt, gpoint_bands, pfrac, blay, blev, lay, lev, stream);
     if (rc == 0)
         rc = lw_solver_noscat_impl<F>(ncol, nlay, ngpt, top_at_1, 1, secants, weights, tau, lay, lev, sfc_emis, sfc_src, inc_flux,
                                       (F*)nullptr, (F*)nullptr, Bool(1), flux_up_loc, flux_dn_loc, Bool(0), (const F*)nullptr, (F*)nullptr, stream);
-    (void)hipFreeAsync(lay, st);
     return rc;
 }
 }  // namespace

@@ -108,8 +108,11 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // requested right after the two-stream phase of g-point g, when the registers of its temporaries are free, and land
 // during the scans and replays; the next iteration finds them in registers. Measured at C4 (tools/sw_lab.hip): 5.3 -> 4.7 ms;
 // loads issued layer by layer inside the two-stream phase were still in flight when their layer came up.
-template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false>
-__global__ void __launch_bounds__(256, (W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)
+// W = 4 (round 3): four wavefronts per column group, eight per workgroup (two column groups, as with W = 2): columns of up to 287
+// layers at nine layers per lane; the wave totals of a scan are then combined over the group's waves in order (the W = 2 code is
+// the two-wave case of the same composition, kept as it was).
+template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false, int NW = (W > 2 ? 2*W : 4)>
+__global__ void __launch_bounds__(64*NW, (NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES))
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
@@ -119,19 +122,20 @@ sw_2stream_scan_kernel(
 {
     // per-thread private LDS columns (dynamic register indexing is not needed: j is a compile-time constant, but
     // two of the six per-layer arrays live here so that the kernel fits 2 waves per SIMD)
-    __shared__ F lds_alb[K*V][256];
-    __shared__ F lds_dir[K*V][256];
-    __shared__ F xch[(W == 2) ? 8*V : 1][4][CL];    // wave totals of the scans (one slot per scan component)
-    __shared__ F lds_acc_up[BB ? K*V : 1][256];
-    __shared__ F lds_acc_dn[BB ? K*V : 1][256];
+    __shared__ F lds_alb[K*V][64*NW];
+    __shared__ F lds_dir[K*V][64*NW];
+    __shared__ F xch[(W >= 2) ? 8*V : 1][NW][CL];   // wave totals of the scans (one slot per scan component)
+    __shared__ F lds_acc_up[BB ? K*V : 1][64*NW];
+    __shared__ F lds_acc_dn[BB ? K*V : 1][64*NW];
 
     const int tid = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
     const int ll = lane >> 3;
-    const int h = (W == 2) ? (wave & 1) : 0;          // which half of the column this wave holds (0 = TOA side)
-    const int wave_col0 = (blockIdx.x*(4/W) + wave/W) * (CL*V);
+    const int h = (W >= 2) ? (wave % W) : 0;          // which part of the column this wave holds (0 = TOA side)
+    [[maybe_unused]] const int w0 = wave - h;         // first wave of the column group
+    const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
     if constexpr (W == 1) { if (wave_col0 >= ncol) return; }
 
     // W == 2: every wave stays alive until the last barrier; lanes without a column compute on a clamped one
@@ -171,7 +175,7 @@ sw_2stream_scan_kernel(
     Vec<F,V> nt[PRE ? K : 1], nw[PRE ? K : 1], n_inc, n_adir, n_adif;
     if constexpr (PRE)
     {
-        static_assert(BB && GZ && W == 2, "the pipelined form is the fused broadband kernel without g array");
+        static_assert(BB && GZ && W >= 2, "the pipelined form is the fused broadband kernel without g array");
         const F* __restrict__ tau_0 = tau + size_t(g_begin)*ncl*nlay;
         const F* __restrict__ ssa_0 = ssa + size_t(g_begin)*ncl*nlay;
         #pragma unroll
@@ -308,7 +312,7 @@ sw_2stream_scan_kernel(
         F pe = shfl(pr, lane - CL);
         if (ll == 0) pe = F(1.);
         F ptot = shfl(pr, (LL-1)*CL + cl);
-        if constexpr (W == 2)
+        if constexpr (W >= 2)
         {
             if (ll == LL-1) xch[8*v+0][wave][cl] = pr;
             __syncthreads();
@@ -328,9 +332,25 @@ sw_2stream_scan_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const F other = xch[8*v+0][wave^1][cl];
-            if (h == 1) pe *= other;
-            ptot *= other;
+            if constexpr (W == 2)
+            {
+                const F other = xch[8*v+0][wave^1][cl];
+                if (h == 1) pe *= other;
+                ptot *= other;
+            }
+            else
+            {
+                F above = F(1.), all = F(1.);
+                #pragma unroll
+                for (int w=0; w<W; ++w)
+                {
+                    const F o = xch[8*v+0][w0+w][cl];
+                    if (w < h) above *= o;
+                    all *= o;
+                }
+                pe *= above;
+                ptot = all;
+            }
         }
         const F dir_top = inc_dir.v[v] * mu.v[v];
         dir_in[v] = dir_top * pe;
@@ -385,6 +405,29 @@ sw_2stream_scan_kernel(
                 m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
             }
         }
+        else if constexpr (W > 2)
+        {
+            if (ll == 0) { xch[8*v+1][wave][cl] = m00; xch[8*v+2][wave][cl] = m01; xch[8*v+3][wave][cl] = m10; }
+            __syncthreads();
+            // composite of the waves below this one (the lowest applied first), then this wave's on top of it
+            #pragma unroll
+            for (int w=W-1; w>=1; --w)
+                if (w > h)
+                {
+                    const F o00 = xch[8*v+1][w0+w][cl], o01 = xch[8*v+2][w0+w][cl], o10 = xch[8*v+3][w0+w][cl];
+                    const F n00 = o00*x00 + o01*x10, n01 = o00*x01 + o01;
+                    const F n10 = o10*x00 + x10,     n11 = o10*x01 + F(1.);
+                    const F inv = fast_rcp(n11);
+                    x00 = n00*inv; x01 = n01*inv; x10 = n10*inv;
+                }
+            if (h < W-1)
+            {
+                const F n00 = m00*x00 + m01*x10, n01 = m00*x01 + m01;
+                const F n10 = m10*x00 + x10,     n11 = m10*x01 + F(1.);
+                const F inv = fast_rcp(n11);
+                m00 = n00*inv; m01 = n01*inv; m10 = n10*inv;
+            }
+        }
         F e00 = shfl(m00, lane + CL), e01 = shfl(m01, lane + CL), e10 = shfl(m10, lane + CL);
         if (ll == LL-1) { e00 = x00; e01 = x01; e10 = x10; }
         const F alb_sfc = a_dif.v[v];
@@ -428,6 +471,15 @@ sw_2stream_scan_kernel(
                 sbb = sa*xb + sbb; sa = sa*xa;
             }
         }
+        else if constexpr (W > 2)
+        {
+            if (ll == 0) { xch[8*v+4][wave][cl] = sa; xch[8*v+5][wave][cl] = sbb; }
+            __syncthreads();
+            #pragma unroll
+            for (int w=W-1; w>=1; --w)
+                if (w > h) { const F oa = xch[8*v+4][w0+w][cl], ob = xch[8*v+5][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
+            if (h < W-1) { sbb = sa*xb + sbb; sa = sa*xa; }
+        }
         F ae = shfl(sa, lane + CL), be = shfl(sbb, lane + CL);
         if (ll == LL-1) { ae = xa; be = xb; }
         const F src_sfc = dir_sfc * a_dir.v[v];
@@ -464,6 +516,15 @@ sw_2stream_scan_kernel(
                 xa = xch[8*v+6][wave^1][cl]; xb = xch[8*v+7][wave^1][cl];
                 db = da*xb + db; da = da*xa;
             }
+        }
+        else if constexpr (W > 2)
+        {
+            if (ll == LL-1) { xch[8*v+6][wave][cl] = da; xch[8*v+7][wave][cl] = db; }
+            __syncthreads();
+            #pragma unroll
+            for (int w=0; w<W-1; ++w)
+                if (w < h) { const F oa = xch[8*v+6][w0+w][cl], ob = xch[8*v+7][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
+            if (h > 0) { db = da*xb + db; da = da*xa; }
         }
         ae = shfl(da, lane - CL); be = shfl(db, lane - CL);
         if (ll == 0) { ae = xa; be = xb; }
@@ -643,15 +704,16 @@ bool launch_scan(hipStream_t st,
     return false;
 }
 
-template<typename F, int V>
+template<typename F, int V, int W = 2>
 bool launch_scan_bb(hipStream_t st,
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
+    constexpr int NW = (W > 2) ? 2*W : 4;                 // wavefronts per workgroup: two column groups
     const int groups = ceil_div(ncol, 2*CL*V);
-    const int need = ceil_div(nlay+1, LL*2);
-    if (need > 12) return false;
+    const int need = ceil_div(nlay+1, LL*W);
+    if (need > (W > 2 ? 9 : 12)) return false;            // (W = 4: nine layers per lane fill the LDS of a CU)
     const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
@@ -662,26 +724,26 @@ bool launch_scan_bb(hipStream_t st,
     if (nsplit > 1) { up = scratch.get<F>(3*nsplit*nlevcol); dn = up + nsplit*nlevcol; dr = dn + nsplit*nlevcol; }
     const dim3 grid(groups, nsplit);
 #define RRX_SW_K(KK) if (need <= KK) { \
-        if (nsplit > 1 && g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true,true><<<grid, 256, 0, st>>>( \
+        if (nsplit > 1 && g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,W,true,true,true,true><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
-        else if (nsplit > 1 && g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true,false,true><<<grid, 256, 0, st>>>( \
+        else if (nsplit > 1 && g == nullptr) sw_2stream_scan_kernel<F,V,KK,W,true,true,false,true><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
-        else if (nsplit > 1) sw_2stream_scan_kernel<F,V,KK,2,true,false,false,true><<<grid, 256, 0, st>>>( \
+        else if (nsplit > 1) sw_2stream_scan_kernel<F,V,KK,W,true,false,false,true><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
-        else if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,2,true,true,true><<<grid, 256, 0, st>>>( \
+        else if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,W,true,true,true><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
-        else if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,2,true,true><<<grid, 256, 0, st>>>( \
+        else if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,W,true,true><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
-        else sw_2stream_scan_kernel<F,V,KK,2,true,false><<<grid, 256, 0, st>>>( \
+        else sw_2stream_scan_kernel<F,V,KK,W,true,false><<<grid, 64*NW, 0, st>>>( \
             ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
             up, dn, dr, tuning().sync_waves, gper); \
         break; }
-    do { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) } while (false);
+    do { if constexpr (W == 2) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) } else { RRX_SW_K(9) } } while (false);
 #undef RRX_SW_K
     if (nsplit > 1)
     {
@@ -721,19 +783,34 @@ int sw_solver_2stream_impl(
         if (launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                   inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
+        // 192 ... 287 layers: four wavefronts per column group (fp64; the two-column lanes of fp32 do not fit the LDS)
+        if constexpr (sizeof(F) == 8)
+        {
+            if (launch_scan_bb<F,1,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                      inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+                return 0;
+        }
     }
 
     // g == nullptr (asymmetry identically zero) is native to the fused broadband kernels only: the other forms read zeros
-    StreamScratch scratch(st);
-    if (g == nullptr) g = scratch.get<F>(size_t(ncol)*nlay*ngpt, true);
+    // the large temporaries of these forms come from one cached block per stream (rrx::cached_workspace): [g zeros][3 per-g-point
+    // flux arrays][the serial kernel's seven cell / level arrays]
+    const size_t nlevcol = size_t(ncol)*(nlay+1);
+    const size_t w_g = (g == nullptr) ? size_t(ncol)*nlay*ngpt : 0, w_flux = do_broadband ? 3*nlevcol*ngpt : 0;
+    const size_t w_serial = 5*size_t(ncol)*nlay*ngpt + 2*nlevcol*ngpt;
+    F* big = (w_g + w_flux > 0) ? static_cast<F*>(cached_workspace(st, (w_g + w_flux + w_serial)*sizeof(F))) : nullptr;
+    if (g == nullptr)
+    {
+        if (hipMemsetAsync(big, 0, w_g*sizeof(F), st) != hipSuccess) throw std::runtime_error("workspace memset failed");
+        g = big;
+    }
 
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
-    const size_t nlevcol = size_t(ncol)*(nlay+1);
     if (do_broadband)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
             throw std::runtime_error("do_broadband needs flux_*_loc");
-        F* ws = scratch.get<F>(3*nlevcol*ngpt);
+        F* ws = big + w_g;
         up = ws; dn = ws + nlevcol*ngpt; dr = ws + 2*nlevcol*ngpt;
     }
 
@@ -755,8 +832,7 @@ int sw_solver_2stream_impl(
     }
     if (!done)
     {
-        const size_t words = 5*size_t(ncol)*nlay*ngpt + 2*nlevcol*ngpt;
-        F* ws2 = scratch.get<F>(words);
+        F* ws2 = (big != nullptr) ? big + w_g + w_flux : static_cast<F*>(cached_workspace(st, w_serial*sizeof(F)));
         const dim3 grid(ceil_div(ncol, 256), ngpt);
         sw_2stream_serial_kernel<F><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0,
                 sfc_alb_dir, sfc_alb_dif, inc_flux_dir, dif, up, dn, dr, ws2);

@@ -118,6 +118,17 @@ def test_full_solve_matches_oracle(kind, ncol, nlay, top_at_1, clouds, hip_f64, 
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
+@pytest.mark.parametrize("ncol,nlay,top_at_1", [(24, 200, False), (17, 287, True)])
+def test_tall_columns_in_broadband_mode_match_oracle(kind, ncol, nlay, top_at_1, hip_f64, oracle_f64):
+    """144 ... 287 layers (an LES grid with a background profile on top): the fused broadband solvers with eight wavefronts per
+    column group (LW) / four (SW), product chain (fractions form) against the oracle in do_broadband mode."""
+    h, o = _solve_both(hip_f64, oracle_f64, kind, ncol, nlay, top_at_1, False, do_broadband=True)
+    for k in ("flux_up", "flux_dn", "flux_net"):
+        e = cases.rel_err(h[k], o[k])
+        assert e <= (1e-7 if kind == "sw" else 1e-9), f"{kind} {k}: {e:.3e}"
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
 def test_full_solve_fp32_matches_fp32_oracle(kind, hip_f32, oracle_f32):
     """RTE_USE_SP build. Compared with the fp32 oracle, not the fp64 one: the reference arithmetic itself is
     discontinuous in eta at eta == 1 (jeta = min(int(loceta)+1, neta-1) with feta = fmod(loceta, 1),
@@ -129,7 +140,7 @@ def test_full_solve_fp32_matches_fp32_oracle(kind, hip_f32, oracle_f32):
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
 @pytest.mark.parametrize("fused", [False, True], ids=["workspace", "fused"])
-@pytest.mark.parametrize("ncol,nlay,top_at_1", [(70, 60, False), (13, 33, True), (129, 140, False), (8, 16, True)])
+@pytest.mark.parametrize("ncol,nlay,top_at_1", [(70, 60, False), (13, 33, True), (129, 140, False), (8, 16, True), (21, 200, False), (9, 286, True)])
 def test_broadband_mode_equals_sum_of_gpoints(kind, fused, ncol, nlay, top_at_1, hip_f64):
     """do_broadband through the whole chain, in both of its forms (per-g-point fluxes in a workspace + sum, and the
     fused kernels), on ragged column counts (partial wavefronts) and layer counts that pick different tilings."""
