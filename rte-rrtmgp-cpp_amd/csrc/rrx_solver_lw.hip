@@ -886,6 +886,11 @@ bool lw_fused_broadband(
             launch_bb2<F,2,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;
+        // 144 ... 287 layers: eight wavefronts per column group
+        if (ncol % 2 == 0 &&
+            launch_bb2<F,2,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
         return false;
     }
 }

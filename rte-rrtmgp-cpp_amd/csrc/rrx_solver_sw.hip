@@ -783,13 +783,10 @@ int sw_solver_2stream_impl(
         if (launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                   inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
-        // 192 ... 287 layers: four wavefronts per column group (fp64; the two-column lanes of fp32 do not fit the LDS)
-        if constexpr (sizeof(F) == 8)
-        {
-            if (launch_scan_bb<F,1,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                      inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
-                return 0;
-        }
+        // 192 ... 287 layers: four wavefronts per column group
+        if (launch_scan_bb<F,VBB,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                    inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+            return 0;
     }
 
     // g == nullptr (asymmetry identically zero) is native to the fused broadband kernels only: the other forms read zeros

@@ -129,6 +129,14 @@ def test_tall_columns_in_broadband_mode_match_oracle(kind, ncol, nlay, top_at_1,
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_tall_columns_fp32_broadband_mode(kind, hip_f32, oracle_f32):
+    """The same tall-column kernels in the RTE_USE_SP build (two columns per lane), against the fp32 oracle."""
+    h, o = _solve_both(hip_f32, oracle_f32, kind, 24, 230, False, False, do_broadband=True)
+    for k in ("flux_up", "flux_dn", "flux_net"):
+        assert cases.rel_err(h[k], o[k], floor=1e-2) <= (1e-3 if kind == "sw" else 2e-4), k     # (fp32 two-stream scans: as test_c5_fp32_…)
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
 def test_full_solve_fp32_matches_fp32_oracle(kind, hip_f32, oracle_f32):
     """RTE_USE_SP build. Compared with the fp32 oracle, not the fp64 one: the reference arithmetic itself is
     discontinuous in eta at eta == 1 (jeta = min(int(loceta)+1, neta-1) with feta = fmod(loceta, 1),
