@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="print the launch command of a multi-GPU run and exit")
     ap.add_argument("--nlay", type=int, default=140)
     ap.add_argument("--ngpt", type=int, default=256)
+    ap.add_argument("--nbnd", type=int, default=0, help="bands of the synthetic k-distributions (default ngpt/16; --ngpt 128 --nbnd 16 = the shape of the reduced sets, 8 g-points per band)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--flux-mode", default="broadband", choices=["broadband", "per-gpoint"],
                     help="broadband: do_broadband solvers, g-point sums kept on chip (the CPU path's semantics, default); "
@@ -285,7 +286,7 @@ def main():
     be.set_variant(lw=args.lw_variant, sw=args.sw_variant)
     if args.bb_min_groups is not None:
         be.set_broadband_min_groups(args.bb_min_groups)
-    nbnd = args.ngpt // 16
+    nbnd = args.nbnd if args.nbnd else args.ngpt // 16
     kd_lw0 = synthetic.make_kdist("lw", ngpt=args.ngpt, nbnd=nbnd)
     kd_sw0 = synthetic.make_kdist("sw", ngpt=args.ngpt, nbnd=nbnd)
     kd_lw, kd_sw = be.upload_kdist(kd_lw0), be.upload_kdist(kd_sw0)

@@ -359,7 +359,7 @@ tau_absorption_kernel(
         const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
         const int per = (nchunk + todo_nz - 1) / todo_nz;
-        c_lo = part*per; c_hi = min(nchunk, c_lo + per);
+        if (part < todo_nz) { c_lo = part*per; c_hi = min(nchunk, c_lo + per); }      // (part == todo_nz: the whole range, see gas_window_kernel)
         const int q = (c_hi - c_lo + GSH - 1) / GSH;
         c_lo += share*q; c_hi = min(c_hi, c_lo + q);
         if (c_lo >= c_hi) continue;
@@ -1119,7 +1119,8 @@ planck_fraction_kernel(
         const int part = entry / todo_nblk, blk = entry % todo_nblk;
         blk_x = blk % todo_gx; blk_y = blk / todo_gx;
         const int nchunk = (ngpt + GCH - 1) / GCH, per = (nchunk + todo_nz - 1) / todo_nz;
-        int c_lo = part*per, c_hi = min(nchunk, c_lo + per);
+        int c_lo = 0, c_hi = nchunk;
+        if (part < todo_nz) { c_lo = part*per; c_hi = min(nchunk, c_lo + per); }      // (part == todo_nz: the whole range)
         const int q = (c_hi - c_lo + GSH - 1) / GSH;
         c_lo += share*q; c_hi = min(c_hi, c_lo + q);
         if (c_lo >= c_hi) continue;
@@ -1240,6 +1241,9 @@ planck_fraction_kernel(
 #ifndef RRX_GW_LDSDMA
 #define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
+#ifndef RRX_GW_BANDCHUNKS
+#define RRX_GW_BANDCHUNKS 1   // chunks end where the flavor or the contributor set changes (0: every 16 g-points, the cut of rounds 1-3; A/B runs)
+#endif
 #ifndef RRX_GW_SPARSE
 #define RRX_GW_SPARSE 1   // only the nodes the workgroup's cells reach are staged (their extent in pressure, eta and temperature), through registers
 #endif
@@ -1316,19 +1320,29 @@ template<typename F> struct PlanckArgs
     F totplnk_delta; const F* totplnk; F* pfrac; F* blay; F* blev; F* sfc_src; F* sfc_src_jac;
 };
 
-// ints of the windowed kernel's index tables (a multiple of four: they travel as 16-byte words)
-inline __host__ __device__ int gas_window_table_ints(const int ngpt, const int nmax)
+// Index tables of the windowed kernel (ints; a multiple of four: they travel as 16-byte words). The g-point loop of a workgroup
+// runs chunk by chunk; a chunk is a run of at most GCH g-points inside which nothing changes -- neither the flavor of either regime
+// nor the set of minor contributors -- so chunks end where bands end (16-g-point bands: the chunks of rounds 1-3; the 8-g-point
+// bands of the reduced k-distributions, g128 / g112: chunks of 8 -- cut every 16 g-points regardless of the bands, 24 % of their
+// workgroups were handed back and the rest ran at half the rate). `ncmax` bounds the number of chunks (host: ngpt/16 + nband).
+struct GasWindowTables
 {
-    const int nchunk = (ngpt + GCH - 1) / GCH;
-    return (2*ngpt + 2*nchunk*(1 + ITEM*NCW) + 2*MM*nmax + 4*nchunk + 3) & ~3;
-}
+    int ngpt, nmax, ncmax;
+    static constexpr int LIT = 1 + NCW;                      // per chunk and regime: count (uncapped), then up to NCW contributor indices
+    __host__ __device__ int off_cinfo() const { return 2*ngpt; }                         // [0] chunks, [1] regular, [2 + c] first g-point of chunk c (ncmax + 1)
+    __host__ __device__ int off_lists() const { return off_cinfo() + ncmax + 3; }        // [2][ncmax][LIT]
+    __host__ __device__ int off_mmeta() const { return off_lists() + 2*ncmax*LIT; }      // [2][nmax][MM]
+    __host__ __device__ int off_cuni()  const { return off_mmeta() + 2*MM*nmax; }        // [2][ncmax] chunk usable by the windowed path
+    __host__ __device__ int off_order() const { return off_cuni() + 2*ncmax; }           // [2][ncmax] chunk order (flavor by flavor)
+    __host__ __device__ int ints()      const { return (off_order() + 2*ncmax + 3) & ~3; }
+};
+inline int gas_window_ncmax(const int ngpt, const int nband) { return (ngpt + GCH - 1) / GCH + std::max(nband, 0); }
 
-// Index tables of the windowed kernel -- g-point flavors, the contributors' metadata, per-chunk contributor lists and the chunk
-// usability flags -- depend on the k-distribution alone. One small workgroup builds them per launch; the 9 000 workgroups of the
-// windowed kernel copy 9 KB instead of each walking the contributor arrays (set-up 0.40 -> 0.30 of 3.5 ms at C4).
+// The tables depend on the k-distribution alone. One small workgroup builds them per launch; the 9 000 workgroups of the windowed
+// kernel copy a few KB instead of each walking the contributor arrays (set-up 0.40 -> 0.30 of 3.5 ms at C4).
 __global__ void __launch_bounds__(256)
 gas_window_tables_kernel(
-        const int ngpt, const int nminorlower, const int nminorupper,
+        const int ngpt, const int nminorlower, const int nminorupper, const int ncmax,
         const int* __restrict__ gpoint_flavor,
         const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
         const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
@@ -1339,16 +1353,19 @@ gas_window_tables_kernel(
         int* __restrict__ tbl)
 {
     extern __shared__ int lds_int[];
-    const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
-    constexpr int LCAP = 1 + ITEM*NCW;
+    const GasWindowTables T{ngpt, nmax, ncmax};
+    constexpr int LIT = GasWindowTables::LIT;
     int* gflav = lds_int;                                   // [2][ngpt]
-    int* lists = lds_int + 2*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
-    int* mmeta = lists + 2*nchunk*LCAP;                     // [2][nmax][MM]
-    int* cuni = mmeta + 2*MM*nmax;                          // [2][nchunk]: chunk usable by the windowed path (per regime)
+    int* cinfo = lds_int + T.off_cinfo();
+    int* lists = lds_int + T.off_lists();
+    int* mmeta = lds_int + T.off_mmeta();
+    int* cuni = lds_int + T.off_cuni();
+    int* order = lds_int + T.off_order();
+    int* cut = lds_int + T.ints();                          // [ngpt + 1] scratch: 1 where a chunk must start
     const int tid = threadIdx.x;
-    const int ntab = gas_window_table_ints(ngpt, nmax);
-    for (int w = tid; w < ntab; w += 256) lds_int[w] = 0;
+    const int ntab = T.ints();
+    for (int w = tid; w < ntab + ngpt + 1; w += 256) lds_int[w] = 0;
     __syncthreads();
     {
         for (int w = tid; w < 2*ngpt; w += 256) gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
@@ -1368,14 +1385,53 @@ gas_window_tables_kernel(
         }
     }
     __syncthreads();
+    // ---- where chunks must start: a flavor change in either regime, the first g-point of a contributor's interval, the g-point
+    // behind its last
+    for (int g = tid; g < ngpt; g += 256)
+        if (g > 0 && (gflav[g] != gflav[g-1] || gflav[ngpt + g] != gflav[ngpt + g-1])) cut[g] = 1;
+    for (int w = tid; w < 2*nmax; w += 256)
+    {
+        const int r = w / nmax, i = w % nmax;
+        if (i < (r == 0 ? nminorlower : nminorupper))
+        {
+            const int* m = mmeta + MM*w;
+            const int lo = m[4]-1, hi = m[5];
+            if (lo > 0 && lo < ngpt) cut[lo] = 1;
+            if (hi > 0 && hi < ngpt) cut[hi] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        int n = 0, start = 0;
+        bool fits = true;
+        for (int g=1; g<=ngpt; ++g)
+            if (g == ngpt || cut[g] || g - start == GCH)
+            {
+                if (n < ncmax) cinfo[2 + n] = start; else fits = false;
+                ++n; start = g;
+            }
+        if (!fits || !RRX_GW_BANDCHUNKS)                     // (more runs than the bound allows for: the plain 16-g-point cut; what does not
+        {                                                    //  fit the staged form there is handed back, as in rounds 1-3)
+            n = (ngpt + GCH - 1) / GCH;
+            for (int c=0; c<n; ++c) cinfo[2 + c] = c*GCH;
+        }
+        cinfo[2 + n] = ngpt;
+        cinfo[0] = n;
+        bool regular = true;
+        for (int c=0; c<n; ++c) regular = regular && (cinfo[2 + c] == c*GCH);
+        cinfo[1] = regular ? 1 : 0;
+    }
+    __syncthreads();
+    const int nchunk = cinfo[0];
     // per-chunk contributor lists (ascending index = the reference's summation order) and the usability flag of the chunk:
     // one flavor over the chunk, every contributor on that flavor, at most NCW of them
     for (int w = tid; w < 2*nchunk; w += 256)
     {
         const int r = w / nchunk, c = w % nchunk;
         const int n = r == 0 ? nminorlower : nminorupper;
-        const int c0 = c*GCH, c1 = min(c0 + GCH, ngpt);
-        int* out = lists + (r*nchunk + c)*LCAP;
+        const int c0 = cinfo[2 + c], c1 = cinfo[3 + c];
+        int* out = lists + (r*ncmax + c)*LIT;
         const int fl = gflav[r*ngpt + c0];
         bool ok = true;
         for (int ig=c0+1; ig<c1; ++ig) ok = ok && (gflav[r*ngpt + ig] == fl);
@@ -1386,42 +1442,46 @@ gas_window_tables_kernel(
             const int lo = m[4]-1, hi = m[5];
             if (lo < c1 && hi > c0)
             {
-                if (cnt < NCW)
-                {
-                    int* it = out + 1 + ITEM*cnt;
-                    it[0] = i; it[1] = lo; it[2] = hi; it[3] = m[6]-1 - lo; it[4] = gflav[r*ngpt + lo];
-                    ok = ok && (it[4] == fl);
-                }
+                if (cnt < NCW) { out[1 + cnt] = i; ok = ok && (gflav[r*ngpt + lo] == fl); }
                 ++cnt;
             }
         }
         out[0] = cnt;
-        cuni[w] = (ok && cnt <= NCW) ? 1 : 0;
+        cuni[r*ncmax + c] = (ok && cnt <= NCW) ? 1 : 0;
     }
     // chunk order per regime: chunks of one flavor next to each other (stable), so that a workgroup evaluates each flavor's
     // interpolation state once instead of once per band that uses it
     if (tid < 2)
     {
-        int* ord = cuni + 2*nchunk + tid*nchunk;
+        int* ord = order + tid*ncmax;
         int k = 0;
         for (int c=0; c<nchunk; ++c)
         {
-            const int fl = gflav[tid*ngpt + c*GCH];
+            const int fl = gflav[tid*ngpt + cinfo[2 + c]];
             bool seen = false;
-            for (int d=0; d<c; ++d) seen = seen || (gflav[tid*ngpt + d*GCH] == fl);
+            for (int d=0; d<c; ++d) seen = seen || (gflav[tid*ngpt + cinfo[2 + d]] == fl);
             if (seen) continue;
-            for (int d=c; d<nchunk; ++d) if (gflav[tid*ngpt + d*GCH] == fl) ord[k++] = d;
+            for (int d=c; d<nchunk; ++d) if (gflav[tid*ngpt + cinfo[2 + d]] == fl) ord[k++] = d;
         }
     }
 
     __syncthreads();
+#ifdef RRX_GW_DEBUG_TABLES
+    if (tid == 0)
+    {
+        printf("tables: ngpt %d ncmax %d chunks %d regular %d\n", ngpt, ncmax, cinfo[0], cinfo[1]);
+        for (int c=0; c<nchunk; ++c)
+            printf("  chunk %d [%d,%d) lower: n %d usable %d fl %d | upper: n %d usable %d fl %d\n", c, cinfo[2+c], cinfo[3+c],
+                   lists[c*LIT], cuni[c], gflav[cinfo[2+c]], lists[(ncmax + c)*LIT], cuni[ncmax + c], gflav[ngpt + cinfo[2+c]]);
+    }
+#endif
     for (int w = tid; w < ntab; w += 256) tbl[w] = lds_int[w];
 }
 
 template<typename F>
-size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int mode, const bool pf)
+size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int ncmax, const int mode, const bool pf)
 {
-    const size_t ints = size_t(gas_window_table_ints(ngpt, nmax)) + 16;
+    const size_t ints = size_t(GasWindowTables{ngpt, nmax, ncmax}.ints()) + 16;
     const size_t pairs = size_t(GCH)*WBOX*(pf ? 2 : 1) + size_t(NCW)*GCH*MBOX + (mode == 1 ? size_t(GCH)*MBOX : 0);
     return ((ints*sizeof(int) + 15) & ~size_t(15)) + pairs*2*sizeof(F);
 }
@@ -1445,7 +1505,7 @@ gas_window_kernel(
         const F* __restrict__ play, const F* __restrict__ tlay, const F* __restrict__ col_gas, const F* __restrict__ col_dry,
         const F* __restrict__ krayl, const InterpArgs<F> ia,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g, const PlanckArgs<F> pa,
-        int* __restrict__ todo, const int geom, const int* __restrict__ tbl)
+        int* __restrict__ todo, const int geom, const int* __restrict__ tbl, const int ncmax)
 {
     // The product chain's kernel: multiply-adds of the node sums are contracted into FMAs here and the single-scattering albedo
     // uses a Newton reciprocal (one rounding fewer per term: 1e-15 relative from the gather / reference-shaped kernels, which
@@ -1456,15 +1516,17 @@ gas_window_kernel(
     typedef F Vec2u __attribute__((ext_vector_type(2), aligned(sizeof(F))));
     (void)sizeof(Vec2u);
     extern __shared__ int lds_int[];
-    const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = max(nminorlower, nminorupper);
-    constexpr int LCAP = 1 + ITEM*NCW;
+    const GasWindowTables T{ngpt, nmax, ncmax};             // layout of the copied tables (gas_window_tables_kernel)
+    constexpr int LIT = GasWindowTables::LIT;
     int* gflav = lds_int;                                   // [2][ngpt]
-    int* lists = lds_int + 2*ngpt;                          // [2][nchunk][LCAP]: count (uncapped), then up to NCW items
-    int* mmeta = lists + 2*nchunk*LCAP;                     // [2][nmax][MM]
-    int* cuni = mmeta + 2*MM*nmax;                          // [2][nchunk]: chunk usable by the windowed path (per regime)
-    int* red = lds_int + gas_window_table_ints(ngpt, nmax);  // [16] workgroup reductions (behind the copied tables)
-    const size_t int_bytes = ((size_t(gas_window_table_ints(ngpt, nmax)) + 16)*sizeof(int) + 15) & ~size_t(15);
+    const int* cinfo = lds_int + T.off_cinfo();             // [0] chunks, [1] regular (every chunk starts at a multiple of GCH), [2 + c] first g-point of chunk c
+    const int* cstart = cinfo + 2;
+    int* lists = lds_int + T.off_lists();                   // [2][ncmax][LIT]: count (uncapped), then up to NCW contributor indices
+    int* mmeta = lds_int + T.off_mmeta();                   // [2][nmax][MM]
+    int* cuni = lds_int + T.off_cuni();                     // [2][ncmax]: chunk usable by the windowed path (per regime)
+    int* red = lds_int + T.ints();                          // [16] workgroup reductions (behind the copied tables)
+    const size_t int_bytes = ((size_t(T.ints()) + 16)*sizeof(int) + 15) & ~size_t(15);
     Vec2* Wmaj = reinterpret_cast<Vec2*>(reinterpret_cast<char*>(lds_int) + int_bytes);     // [GCH][WBOX]
     Vec2* Wpf  = Wmaj + GCH*WBOX;                                                           // [GCH][WBOX] (PF)
     Vec2* Wmin = Wpf + (PF ? GCH*WBOX : 0);                                                 // [NCW][GCH][MBOX]
@@ -1476,7 +1538,7 @@ gas_window_kernel(
 #endif
     // the index tables depend on the k-distribution alone: gas_window_tables_kernel built them once for this launch
     {
-        const int n4 = gas_window_table_ints(ngpt, nmax) / 4;
+        const int n4 = T.ints() / 4;
         const int4* __restrict__ src = reinterpret_cast<const int4*>(tbl);
         int4* dst = reinterpret_cast<int4*>(lds_int);
         for (int w = tid; w < n4; w += 256) dst[w] = src[w];
@@ -1502,13 +1564,19 @@ gas_window_kernel(
     atomicMin(&red[4], itr); atomicMax(&red[5], itr);
     __syncthreads();
     const int jt_lo = red[0], jp_lo = red[2];
-    // grid.z parts share out the chunks of a workgroup when the (column, layer) grid alone leaves CUs idle (few columns per GPU)
-    const int c_per = (nchunk + int(gridDim.z) - 1) / int(gridDim.z);
-    const int c_lo = int(blockIdx.z)*c_per, c_hi = min(nchunk, c_lo + c_per);
+    // grid.z parts share out the chunks of a workgroup when the (column, layer) grid alone leaves CUs idle (few columns per GPU).
+    // A part is a range of 16-g-point stretches, which the gather kernel can redo from the part's number alone; where the chunks do
+    // not start at multiples of 16 (band-aligned chunks of a reduced k-distribution) part 0 takes them all and hands back "the
+    // whole range" (part = gridDim.z).
+    const int nchunk = rfl(cinfo[0]);
+    const bool whole_range = gridDim.z > 1 && rfl(cinfo[1]) == 0;
+    if (whole_range && blockIdx.z > 0) return;
+    const int c_per = whole_range ? nchunk : (nchunk + int(gridDim.z) - 1) / int(gridDim.z);
+    const int c_lo = whole_range ? 0 : int(blockIdx.z)*c_per, c_hi = min(nchunk, c_lo + c_per);
     bool fits = (red[1] - jt_lo < NTW) && (red[3] - jp_lo + 2 <= NPW) && (red[4] == red[5]);
     {
         bool all_chunks = true;
-        for (int c=c_lo; c<c_hi; ++c) all_chunks = all_chunks && (cuni[itr*nchunk + c] != 0);
+        for (int c=c_lo; c<c_hi; ++c) all_chunks = all_chunks && (cuni[itr*ncmax + c] != 0);
         fits = fits && all_chunks;
     }
     // workgroup-uniform: the gather kernel redoes this workgroup from scratch. The eight words in front of the list count the
@@ -1519,7 +1587,7 @@ gas_window_kernel(
         if (tid == 0)
         {
             const int k = atomicAdd(&todo[0], 1);
-            todo[1 + k] = int(blockIdx.y*gridDim.x + blockIdx.x) + int(blockIdx.z)*int(gridDim.x*gridDim.y);
+            todo[1 + k] = int(blockIdx.y*gridDim.x + blockIdx.x) + int(whole_range ? gridDim.z : blockIdx.z)*int(gridDim.x*gridDim.y);
             atomicAdd(&todo[why - 8], 1);
         }
     };
@@ -1591,11 +1659,17 @@ gas_window_kernel(
 
     if (RRX_GW_ABL == 1) return;
     RRX_GW_T(0)
-    const int* corder = cuni + 2*nchunk + rfl(itr)*nchunk;             // (one regime per workgroup here)
+    const int* corder = lds_int + T.off_order() + rfl(itr)*ncmax;      // (one regime per workgroup here)
+    // per contributor of the chunk: first g-point, end, offset of its kminor rows (from the metadata table)
+    auto item_meta = [&](const int* items, const int i, int& lo, int& hi, int& koff)
+    {
+        const int* m = mmeta + MM*(rfl(itr)*nmax + rfl(items[i]));
+        lo = rfl(m[4]) - 1; hi = rfl(m[5]); koff = rfl(m[6]) - 1 - lo;
+    };
     for (int kc=c_lo; kc<c_hi; ++kc)
     {
-        const int c = (gridDim.z == 1) ? rfl(corder[kc]) : kc;          // (parts of the chunk range keep the natural order: the gather kernel redoes a handed-back part by its range)
-        const int c0 = c*GCH, gend = min(c0 + GCH, ngpt), ng = gend - c0;
+        const int c = (gridDim.z == 1 || whole_range) ? rfl(corder[kc]) : kc;   // (parts of the chunk range keep the natural order)
+        const int c0 = rfl(cstart[c]), gend = rfl(cstart[c+1]), ng = gend - c0;
         const int fl = gflav[itr*ngpt + c0];
         if (fl != cur_flav)                                            // workgroup-uniform
         {
@@ -1628,8 +1702,8 @@ gas_window_kernel(
         // (the regime is the same in every lane here: readfirstlane moves the chunk's list into scalar registers, so that the
         //  contributor conditions of the g-point loop are scalar branches instead of exec-mask sequences)
         const int itr_s = rfl(itr);
-        const int n = rfl(lists[(itr_s*nchunk + c)*LCAP]);
-        const int* items = lists + (itr_s*nchunk + c)*LCAP + 1;
+        const int n = rfl(lists[(itr_s*ncmax + c)*LIT]);
+        const int* items = lists + (itr_s*ncmax + c)*LIT + 1;            // contributor indices of the chunk
 
         RRX_GW_T(1)
         __syncthreads();                        // the previous chunk's readers are done with the windows
@@ -1685,7 +1759,7 @@ gas_window_kernel(
                     const F* kmin_u = rfl(itr) == 0 ? kminor_lower : kminor_upper;
                     auto minor_node = [&](const int i) -> Vec2
                     {
-                        const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                        int lo, hi, koff; item_meta(items, i, lo, hi, koff);
                         const int kg = min(max(c0 + gi_m, lo), hi-1);                   // clamped: always a valid table row
                         return *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(kmin_u) + unsigned((kg + koff)*tn)*SZ + roff);
                     };
@@ -1745,7 +1819,7 @@ gas_window_kernel(
                 for (int i=0; i<NCW; ++i)
                     if (i < n)
                     {
-                        const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                        int lo, hi, koff; item_meta(items, i, lo, hi, koff);
                         const int kg = min(max(c0 + gi_m, lo), hi-1);       // clamped: always a valid table row
                         glds(byte_off(kmin_u, unsigned((kg + koff)*tn + it_m + ie_m*ntemp)*SZ), Wmin + i*GCH*MBOX + tid);
                     }
@@ -1798,7 +1872,7 @@ gas_window_kernel(
             const int it_m = min(jt_lo - 1 + r_m % NTW, ntemp-2), ie_m = min(max(je_lo - 1 + r_m / NTW, 0), neta-1);
             auto minor_node = [&](const int i) -> Vec2
             {
-                const int lo = items[ITEM*i+1], hi = items[ITEM*i+2], koff = items[ITEM*i+3];
+                int lo, hi, koff; item_meta(items, i, lo, hi, koff);
                 const int kg = min(max(c0 + gi_m, lo), hi-1);                   // clamped: always a valid table row
                 return *reinterpret_cast<const Vec2u*>(kmin + size_t(kg + koff)*tn + it_m + ie_m*ntemp);
             };
@@ -1828,7 +1902,7 @@ gas_window_kernel(
         for (int i=0; i<NCW; ++i)
         {
             sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
-            if (i < n) { sc[i] = minor_scaling(rfl(items[ITEM*i])); slo[i] = rfl(items[ITEM*i+1]); shi[i] = rfl(items[ITEM*i+2]); }
+            if (i < n) { int koff_; sc[i] = minor_scaling(rfl(items[i])); item_meta(items, i, slo[i], shi[i], koff_); }
         }
         RRX_GW_T(7)
         __syncthreads();
@@ -2103,7 +2177,7 @@ int gas_optics_lw_fractions_impl(
         F* tau, F* pfrac, F* blay, F* blev, F* sfc_src, F* sfc_src_jac, void* stream)
 {
     RRX_TRY
-    (void)nband; (void)ngas; (void)nflav;
+    (void)ngas; (void)nflav;
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunk = (ngpt + GCH - 1) / GCH;
@@ -2112,7 +2186,8 @@ int gas_optics_lw_fractions_impl(
     if (lds > 64*1024) throw std::runtime_error("minor-gas index exceeds 64 KiB of LDS");
     const dim3 block(64, 4);
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
-    const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, 2, true);
+    const int ncmax = gas_window_ncmax(ngpt, nband);
+    const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, 2, true);
     const bool windowed = tuning().go_window && wlds <= 64*1024;
     StreamScratch scratch(st);
     const int geom = gas_window_geometry(ncol);
@@ -2124,9 +2199,10 @@ int gas_optics_lw_fractions_impl(
     {
         todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
-        int* tbl = scratch.get<int>(size_t(gas_window_table_ints(ngpt, nmax)));
-        gas_window_tables_kernel<<<1, 256, size_t(gas_window_table_ints(ngpt, nmax))*sizeof(int), st>>>(
-                ngpt, nminorlower, nminorupper, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+        const GasWindowTables T{ngpt, nmax, ncmax};
+        int* tbl = scratch.get<int>(size_t(T.ints()));
+        gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 1)*sizeof(int), st>>>(
+                ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                 minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                 kminor_start_lower, kminor_start_upper, tbl);
@@ -2137,7 +2213,7 @@ int gas_optics_lw_fractions_impl(
                 scale_by_complement_lower, scale_by_complement_upper, \
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                 kminor_start_lower, kminor_start_upper, play, tlay, col_gas, (const F*)nullptr, (const F*)nullptr, ia, \
-                tau, (F*)nullptr, (F*)nullptr, pa, todo, geom, tbl
+                tau, (F*)nullptr, (F*)nullptr, pa, todo, geom, tbl, ncmax
         if (ia.cld_tau != nullptr) gas_window_kernel<F,2,true,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
         else gas_window_kernel<F,2,true><<<dim3(wgrid.x, wgrid.y, nz), block, wlds, st>>>(RRX_GW_PF_ARGS);
 #undef RRX_GW_PF_ARGS
@@ -2180,7 +2256,7 @@ int tau_absorption_impl(
         F* tau, F* ssa, F* g, void* stream, const char* name, const InterpArgs<F> ia = InterpArgs<F>())
 {
     RRX_TRY
-    (void)nband; (void)ngas; (void)nflav; (void)band_lims_gpt; (void)nminorklower; (void)nminorkupper;
+    (void)ngas; (void)nflav; (void)band_lims_gpt; (void)nminorklower; (void)nminorkupper;
     if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
     const int nchunk = (ngpt + GCH - 1) / GCH;
     const int nmax = std::max(nminorlower, nminorupper);
@@ -2191,7 +2267,8 @@ int tau_absorption_impl(
     if constexpr (DIRECT && MODE != 0)
     {
         // windowed kernel first; the gather kernel then finishes the workgroups it handed back (usually none)
-        const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, MODE, false);
+        const int ncmax = gas_window_ncmax(ngpt, nband);
+        const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, MODE, false);
         if (tuning().go_window && wlds <= 64*1024)
         {
             hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2202,9 +2279,10 @@ int tau_absorption_impl(
             const int nz = gas_window_parts(nblk, nchunk);
             int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
-            int* tbl = scratch.get<int>(size_t(gas_window_table_ints(ngpt, nmax)));
-            gas_window_tables_kernel<<<1, 256, size_t(gas_window_table_ints(ngpt, nmax))*sizeof(int), st>>>(
-                    ngpt, nminorlower, nminorupper, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+            const GasWindowTables T{ngpt, nmax, ncmax};
+            int* tbl = scratch.get<int>(size_t(T.ints()));
+            gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 1)*sizeof(int), st>>>(
+                    ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                     kminor_start_lower, kminor_start_upper, tbl);
@@ -2214,7 +2292,7 @@ int tau_absorption_impl(
                     scale_by_complement_lower, scale_by_complement_upper, \
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper, \
                     kminor_start_lower, kminor_start_upper, play, tlay, col_gas, col_dry, krayl, ia, tau, ssa, g, \
-                    PlanckArgs<F>(), todo, geom, tbl
+                    PlanckArgs<F>(), todo, geom, tbl, ncmax
 #define RRX_TA_ARGS ncol, nlay, ngpt, neta, npres, ntemp, nminorlower, nminorupper, idx_h2o, gpoint_flavor, \
                     kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, \
                     minor_scales_with_density_lower, minor_scales_with_density_upper, \
