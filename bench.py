@@ -195,7 +195,7 @@ def local_atmosphere(args, nbnd, rank, world):
     if getattr(args, "allsky", False):     # the all-sky atmosphere (cloud mask) is built as a whole and sharded: see main()
         return (s, e), None
     # only this rank's columns are built (column c is the same column whatever the number of ranks)
-    atm = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e))
+    atm = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e), top_at_1=getattr(args, "top_at_1", False))
     if getattr(args, "col_spread", 0.0) > 0:
         atm = spread_columns(atm, args.col_spread, s, e, ntot)
     return (s, e), atm
@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="print the launch command of a multi-GPU run and exit")
     ap.add_argument("--nlay", type=int, default=140)
     ap.add_argument("--ngpt", type=int, default=256)
+    ap.add_argument("--top-at-1", action="store_true", help="columns ordered from the top of the atmosphere down (the default is surface first, as the reference's RCEMIP case)")
     ap.add_argument("--nbnd", type=int, default=0, help="bands of the synthetic k-distributions (default ngpt/16; --ngpt 128 --nbnd 16 = the shape of the reduced sets, 8 g-points per band)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--flux-mode", default="broadband", choices=["broadband", "per-gpoint"],
