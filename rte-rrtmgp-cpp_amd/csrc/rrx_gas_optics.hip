@@ -1365,7 +1365,7 @@ gas_window_tables_kernel(
     int* cut = lds_int + T.ints();                          // [ngpt + 1] scratch: 1 where a chunk must start
     const int tid = threadIdx.x;
     const int ntab = T.ints();
-    for (int w = tid; w < ntab + ngpt + 1; w += 256) lds_int[w] = 0;
+    for (int w = tid; w < ntab + ngpt + 4 + 2*((ngpt + 63)/64); w += 256) lds_int[w] = 0;
     __syncthreads();
     {
         for (int w = tid; w < 2*ngpt; w += 256) gflav[(w & 1)*ngpt + (w >> 1)] = gpoint_flavor[w] - 1;
@@ -1401,16 +1401,33 @@ gas_window_tables_kernel(
         }
     }
     __syncthreads();
+    // (the cut flags of 64 g-points as one ballot word each, so that one thread can walk over the cuts instead of over the g-points)
+    unsigned long long* cutmask = reinterpret_cast<unsigned long long*>(cut + ((ngpt + 2) & ~1));      // [(ngpt + 63)/64]
+    for (int base = 0; base < ngpt; base += 256)
+    {
+        const int g = base + tid;
+        const unsigned long long m = __ballot(g > 0 && g < ngpt && cut[g] != 0);
+        if ((tid & 63) == 0 && base + (tid & ~63) < ngpt) cutmask[(base + tid) >> 6] = m;
+    }
+    __syncthreads();
     if (tid == 0)
     {
         int n = 0, start = 0;
         bool fits = true;
-        for (int g=1; g<=ngpt; ++g)
-            if (g == ngpt || cut[g] || g - start == GCH)
+        auto emit_until = [&](const int p)                   // chunks of at most GCH g-points from `start` up to the cut at p
+        {
+            while (start < p)
             {
                 if (n < ncmax) cinfo[2 + n] = start; else fits = false;
-                ++n; start = g;
+                ++n; start = min(start + GCH, p);
             }
+        };
+        for (int w = 0; w < (ngpt + 63)/64; ++w)
+        {
+            unsigned long long m = cutmask[w];
+            while (m != 0ull) { const int b = __ffsll((long long)m) - 1; m &= m - 1ull; emit_until(64*w + b); }
+        }
+        emit_until(ngpt);
         if (!fits || !RRX_GW_BANDCHUNKS)                     // (more runs than the bound allows for: the plain 16-g-point cut; what does not
         {                                                    //  fit the staged form there is handed back, as in rounds 1-3)
             n = (ngpt + GCH - 1) / GCH;
@@ -2201,7 +2218,7 @@ int gas_optics_lw_fractions_impl(
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
         const GasWindowTables T{ngpt, nmax, ncmax};
         int* tbl = scratch.get<int>(size_t(T.ints()));
-        gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 1)*sizeof(int), st>>>(
+        gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
                 ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                 minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
@@ -2281,7 +2298,7 @@ int tau_absorption_impl(
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
             const GasWindowTables T{ngpt, nmax, ncmax};
             int* tbl = scratch.get<int>(size_t(T.ints()));
-            gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 1)*sizeof(int), st>>>(
+            gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
                     ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
