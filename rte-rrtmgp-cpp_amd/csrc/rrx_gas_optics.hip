@@ -2205,7 +2205,8 @@ int gas_optics_lw_fractions_impl(
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
     const int ncmax = gas_window_ncmax(ngpt, nband);
     const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, 2, true);
-    const bool windowed = tuning().go_window && wlds <= 64*1024;
+    // (the windowed kernel addresses a cell inside a g-point slab with a 32-bit byte offset)
+    const bool windowed = tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32);
     StreamScratch scratch(st);
     const int geom = gas_window_geometry(ncol);
     const dim3 wgrid = gas_window_grid(geom, ncol, nlay);
@@ -2286,7 +2287,7 @@ int tau_absorption_impl(
         // windowed kernel first; the gather kernel then finishes the workgroups it handed back (usually none)
         const int ncmax = gas_window_ncmax(ngpt, nband);
         const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, MODE, false);
-        if (tuning().go_window && wlds <= 64*1024)
+        if (tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32))
         {
             hipStream_t st = static_cast<hipStream_t>(stream);
             StreamScratch scratch(st);
