@@ -714,7 +714,8 @@ bool launch_scan_bb(hipStream_t st,
     const int groups = ceil_div(ncol, 2*CL*V);
     const int need = ceil_div(nlay+1, LL*W);
     if (need > (W > 2 ? 9 : 12)) return false;            // (W = 4: nine layers per lane fill the LDS of a CU)
-    const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
+    // (fp32, two columns per lane: the pipelined form needs 140 B of scratch per lane and is slower, 4.00 against 3.63 ms at C4)
+    const bool pre = sizeof(F) == 8 && tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
