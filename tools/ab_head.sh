@@ -1,4 +1,5 @@
-# A/B of the working tree's rrx_gas_optics.hip against a saved copy (tools/_ab_head_gas_optics.hip), ONE box, clear-sky and all-sky
+# A/B of the working tree's rrx_gas_optics.hip against a saved copy, ONE box, clear-sky and all-sky. Before the call:
+#   git show HEAD:rte-rrtmgp-cpp_amd/csrc/rrx_gas_optics.hip > tools/_ab_head_gas_optics.hip   (git-ignored; travels with gpurun)
 export TMPDIR=/tmp
 cp rte-rrtmgp-cpp_amd/csrc/rrx_gas_optics.hip /tmp/new_gas_optics.hip
 for v in new head new head; do
