@@ -333,3 +333,19 @@ def test_driver_solves_differing_columns_in_order_of_surface_pressure(tmp_path, 
     synthetic_files.write_input(os.path.join(d, "rte_rrtmgp_input.nc"), atm2, KW["nbnd"], KW["nbnd"])
     assert run_driver(d) == 0
     assert "order of surface pressure" not in capfd.readouterr().out
+
+
+def test_driver_on_tall_columns_and_narrow_bands(tmp_path, hip_f64):
+    """The C++ driver on a shape beside the usual ones: 200 layers (the eight-wave / four-wave forms of the fused solvers) and
+    8 g-points per band (band-aligned chunks of the windowed gas optics), against the Python pipeline on the same kernels."""
+    kw = dict(ngpt=48, nbnd=6, npres=12, nflav=4, nminor_lower=7, nminor_upper=4)
+    kl, ks = synthetic.make_kdist("lw", **kw), synthetic.make_kdist("sw", **kw)
+    atm = synthetic.make_atmosphere(70, 200, nbnd_lw=kw["nbnd"], nbnd_sw=kw["nbnd"], seed=21)
+    d = str(tmp_path)
+    synthetic_files.write_case(d, atm, kl, ks)
+    c = dict(dir=d, kl=kl, ks=ks, atm=atm, ll=None, ls=None)
+    assert run_driver(d) == 0
+    _, out = read_output(d)
+    ref = reference_fluxes(hip_f64, c, clouds=False)
+    for k in ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net"):
+        assert cases.rel_err(out[k], ref[k]) <= (1e-7 if k.startswith("sw_") else 1e-11), k
