@@ -267,6 +267,7 @@ def main():
     if args.dry_run:
         print(" ".join([sys.executable, os.path.abspath(__file__)] + sys.argv[1:])); return 0
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: RCCL between the ranks of a node needs it on this driver)
     import torch
     import torch.distributed as dist
     import rte_rrtmgp_cpp_amd as R
