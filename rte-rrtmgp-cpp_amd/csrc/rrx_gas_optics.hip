@@ -2127,7 +2127,8 @@ gas_window_kernel(
 #endif
         // (the fractions form and the all-sky SW form have no registers to spare in fp64: paired they spill, and a spill reload waits
         //  behind every store in flight)
-        constexpr int PAIR = (RRX_GW_PAIR && (RRX_GW_PAIR_PF || !(PF && sizeof(F) == 8)) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1 && sizeof(F) == 8)) ? 2 : 1;
+        // (fp32: unpaired is faster in every form -- LW stage 2.05 -> 1.87 ms, SW 1.56 -> 1.50 ms at C4, tools/ab_extra.sh)
+        constexpr int PAIR = (RRX_GW_PAIR && sizeof(F) == 8 && (RRX_GW_PAIR_PF || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
         if (RRX_GW_ABL != 3)
         for (int gi=0; gi<ng; )
         {
