@@ -216,11 +216,14 @@ def test_fused_broadband_solvers_sum_gpoints_in_order(dt, top_at_1, hip_f64, hip
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
-def test_columns_in_different_regimes_within_one_wavefront(kind, hip_f64, oracle_f64):
+@pytest.mark.parametrize("ncol,ngpt,nbnd", [(130, 64, 4), (300, 64, 8)], ids=["16-per-band", "8-per-band-wide-workgroups"])
+def test_columns_in_different_regimes_within_one_wavefront(kind, ncol, ngpt, nbnd, hip_f64, oracle_f64):
     """Columns whose pressure at the same layer differs by up to +-35 %: wavefronts (64 columns of one layer) straddle the
     tropopause and the LUT cell boundaries, i.e. both regime passes of the absorption kernel run, the shared-cell path of
-    the Planck kernel is refused lane by lane, and minor-contributor lists differ between lanes."""
-    ncol, nlay, ngpt, nbnd = 130, 60, 64, 4
+    the Planck kernel is refused lane by lane, and minor-contributor lists differ between lanes. Second shape: 256-column
+    workgroups, band-aligned chunks of 8 g-points and a chunk loop shared out over grid.z, so that workgroups are handed back
+    as "the whole range" of part 0."""
+    nlay = 60
     kd0 = synthetic.make_kdist(kind, ngpt=ngpt, nbnd=nbnd, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
     atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=7)
     rng = np.random.default_rng(8)
