@@ -1251,6 +1251,7 @@ constexpr int NPW = 4, NEW = 4, NTW = 3;
 constexpr int WBOX = NPW*NEW*NTW;            // pair-nodes per g-point: kmajor, planck_frac
 constexpr int MBOX = NEW*NTW;                // pair-nodes per g-point: one minor contributor, Rayleigh
 constexpr int NCW = 6;                       // minor contributors of a chunk with a staged window
+constexpr int NXW = 12;                      // ... and how many a chunk may have at all: those beyond NCW are added in a pass of their own behind the g-point loop
 
 // Parts (grid.z) the chunk loop of the windowed kernel is shared out over: 1 when the (column, layer) workgroups alone fill the
 // chip a few times over (three resident per CU), else 2 or 4
@@ -1328,7 +1329,7 @@ template<typename F> struct PlanckArgs
 struct GasWindowTables
 {
     int ngpt, nmax, ncmax;
-    static constexpr int LIT = 1 + NCW;                      // per chunk and regime: count (uncapped), then up to NCW contributor indices
+    static constexpr int LIT = 1 + NXW;                      // per chunk and regime: count (uncapped), then up to NXW contributor indices
     __host__ __device__ int off_cinfo() const { return 2*ngpt; }                         // [0] chunks, [1] regular, [2 + c] first g-point of chunk c (ncmax + 1)
     __host__ __device__ int off_lists() const { return off_cinfo() + ncmax + 3; }        // [2][ncmax][LIT]
     __host__ __device__ int off_mmeta() const { return off_lists() + 2*ncmax*LIT; }      // [2][nmax][MM]
@@ -1342,7 +1343,7 @@ inline int gas_window_ncmax(const int ngpt, const int nband) { return (ngpt + GC
 // kernel copy a few KB instead of each walking the contributor arrays (set-up 0.40 -> 0.30 of 3.5 ms at C4).
 __global__ void __launch_bounds__(256)
 gas_window_tables_kernel(
-        const int ngpt, const int nminorlower, const int nminorupper, const int ncmax,
+        const int ngpt, const int nminorlower, const int nminorupper, const int ncmax, const int nlist,
         const int* __restrict__ gpoint_flavor,
         const int* __restrict__ minor_limits_gpt_lower, const int* __restrict__ minor_limits_gpt_upper,
         const Bool* __restrict__ minor_scales_with_density_lower, const Bool* __restrict__ minor_scales_with_density_upper,
@@ -1442,7 +1443,8 @@ gas_window_tables_kernel(
     __syncthreads();
     const int nchunk = cinfo[0];
     // per-chunk contributor lists (ascending index = the reference's summation order) and the usability flag of the chunk:
-    // one flavor over the chunk, every contributor on that flavor, at most NCW of them
+    // one flavor over the chunk, every contributor on that flavor, at most `nlist` of them (NXW; NCW where the form of the launch has
+    // no pass for the later ones)
     for (int w = tid; w < 2*nchunk; w += 256)
     {
         const int r = w / nchunk, c = w % nchunk;
@@ -1459,12 +1461,12 @@ gas_window_tables_kernel(
             const int lo = m[4]-1, hi = m[5];
             if (lo < c1 && hi > c0)
             {
-                if (cnt < NCW) { out[1 + cnt] = i; ok = ok && (gflav[r*ngpt + lo] == fl); }
+                if (cnt < nlist) { out[1 + cnt] = i; ok = ok && (gflav[r*ngpt + lo] == fl); }
                 ++cnt;
             }
         }
         out[0] = cnt;
-        cuni[r*ncmax + c] = (ok && cnt <= NCW) ? 1 : 0;
+        cuni[r*ncmax + c] = (ok && cnt <= nlist) ? 1 : 0;
     }
     // chunk order per regime: chunks of one flavor next to each other (stable), so that a workgroup evaluates each flavor's
     // interpolation state once instead of once per band that uses it
@@ -1719,7 +1721,8 @@ gas_window_kernel(
         // (the regime is the same in every lane here: readfirstlane moves the chunk's list into scalar registers, so that the
         //  contributor conditions of the g-point loop are scalar branches instead of exec-mask sequences)
         const int itr_s = rfl(itr);
-        const int n = rfl(lists[(itr_s*ncmax + c)*LIT]);
+        const int n_all = rfl(lists[(itr_s*ncmax + c)*LIT]);             // (at most NXW here: the chunk is usable)
+        const int n = min(n_all, NCW);                                   // contributors of the g-point loop; the others follow behind it
         const int* items = lists + (itr_s*ncmax + c)*LIT + 1;            // contributor indices of the chunk
 
         RRX_GW_T(1)
@@ -2137,6 +2140,47 @@ gas_window_kernel(
             if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, std::false_type{}, gi); gi += 2; }
             else { gstep(std::integral_constant<int,1>{}, std::true_type{}, gi); gi += 1; }
         }
+        // ---- contributors beyond the NCW the boxes have room for (a band of the full gas set can have seven or more): one at a time,
+        // its nodes staged into the first contributor box, its term added to the optical depths this chunk has just stored (and, in the
+        // Rare and slow by design -- the alternative was to hand the whole regime back to the gather kernels. LW forms only: the
+        // bands with seven contributors are longwave ones (1 080-1 180 cm-1 with the CFCs present), and in the SW form the extra code
+        // cost the g-point loop three spilled registers (2.16 -> 2.22 ms, tools/ab_head.sh); its lists end at NCW.
+        if constexpr (MODE == 2)
+        if (n_all > NCW)                                                // workgroup-uniform
+        {
+            const F* kmin_u = rfl(itr) == 0 ? kminor_lower : kminor_upper;
+            for (int x=NCW; x<n_all; ++x)
+            {
+                __syncthreads();                                        // the boxes of the loop (or of the contributor before) are free
+                int xlo, xhi, xk; item_meta(items, x, xlo, xhi, xk);
+                if (tid < GCH*MBOX)
+                {
+                    const int gi_m = min(tid / MBOX, ng-1), r_m = tid % MBOX;
+                    const int it_m = min(jt_lo - 1 + r_m % NTW, ntemp-2), ie_m = min(max(je_lo - 1 + r_m / NTW, 0), neta-1);
+                    const int kg = min(max(c0 + gi_m, xlo), xhi-1);     // clamped: always a valid table row
+                    Wmin[tid] = *reinterpret_cast<const Vec2u*>(kmin_u + size_t(kg + xk)*tn + it_m + ie_m*ntemp);
+                }
+                const F scx = minor_scaling(rfl(items[x]));
+                __syncthreads();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wavefront's stores of the chunk have left: they are read back
+                for (int gi=0; gi<ng; ++gi)
+                {
+                    const int ig = c0 + gi;
+                    if (ig < xlo || ig >= xhi) continue;                // (uniform)
+                    const Vec2* wn = Wmin + gi*MBOX;
+                    const Vec2 c0v = wn[q0], c1v = wn[q0 + NTW];
+                    F m2 = c0v.y, m3 = c1v.y;
+                    if (!wave_same_eta) { m2 = wn[q1].y; m3 = wn[q1 + NTW].y; }
+                    const F add = (fn[0]*c0v.x + fn[1]*c1v.x + fn[2]*m2 + fn[3]*m3) * scx;
+                    F* tp = reinterpret_cast<F*>(reinterpret_cast<char*>(tau + size_t(ig)*ncl) + idx_b);
+                    if (active)
+                    {
+                        const F tt = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;     // (past the L1)
+                        slab_store(tau, ig, tt);
+                    }
+                }
+            }
+        }
         RRX_GW_T(5)
     }
 #if RRX_GW_TIMING
@@ -2223,7 +2267,7 @@ int gas_optics_lw_fractions_impl(
         const GasWindowTables T{ngpt, nmax, ncmax};
         int* tbl = scratch.get<int>(size_t(T.ints()));
         gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
-                ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                ngpt, nminorlower, nminorupper, ncmax, NXW, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                 minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                 idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                 kminor_start_lower, kminor_start_upper, tbl);
@@ -2303,7 +2347,7 @@ int tau_absorption_impl(
             const GasWindowTables T{ngpt, nmax, ncmax};
             int* tbl = scratch.get<int>(size_t(T.ints()));
             gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
-                    ngpt, nminorlower, nminorupper, ncmax, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                    ngpt, nminorlower, nminorupper, ncmax, (MODE == 1) ? NCW : NXW, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
                     idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower, idx_minor_scaling_upper,
                     kminor_start_lower, kminor_start_upper, tbl);

@@ -455,6 +455,35 @@ def _worst(h, o, keys, floor=1e-6):
     return {k: cases.rel_err(h[k], o[k], floor) for k in keys}
 
 
+@pytest.mark.parametrize("nminor_lower,expect_window", [(20, True), (30, True), (40, False)], ids=["up-to-8", "up-to-10", "up-to-13"])
+def test_more_minor_contributors_per_band_than_the_boxes_hold(nminor_lower, expect_window, hip_f64, oracle_f64):
+    """Bands with 7-12 minor contributors in one regime (the full gas set has such a longwave band): the windowed LW kernel adds the
+    ones beyond its six contributor boxes in a pass behind the g-point loop (no workgroup handed back); with more than 12 the regime
+    goes to the gather kernels as before. Both against the oracle, fractions form and plain form."""
+    import ctypes
+    kd0 = synthetic.make_kdist("lw", ngpt=64, nbnd=4, npres=20, nflav=4, nminor_lower=nminor_lower, nminor_upper=9)
+    atm0 = synthetic.make_atmosphere(300, 60, nbnd_lw=4, nbnd_sw=4, seed=9)
+    res = {}
+    for be in (hip_f64, oracle_f64):
+        kd = be.upload_kdist(kd0); atm = pipeline.upload_atmosphere(be, atm0)
+        for bb in (True, False):                # fractions form (broadband chain) and plain form (per-g-point chain)
+            if be is hip_f64:
+                os.environ["RRX_GW_STATS"] = "1"; hip_f64.lib.cdll.rrx_gas_window_stats(None, None, 1)
+            try:
+                r = pipeline.solve_lw(be, kd, atm, keep=True, do_broadband=bb)
+            finally:
+                os.environ.pop("RRX_GW_STATS", None)
+            if be is hip_f64:
+                handed, total = ctypes.c_longlong(0), ctypes.c_longlong(0)
+                hip_f64.lib.cdll.rrx_gas_window_stats(ctypes.byref(handed), ctypes.byref(total), 1)
+                assert total.value > 0 and (handed.value == 0) == expect_window, (handed.value, total.value)
+            res[(be is hip_f64, bb)] = {k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)}
+    for bb in (True, False):
+        h, o = res[(True, bb)], res[(False, bb)]
+        for k in ("tau", "flux_up", "flux_dn", "flux_net"):
+            assert cases.rel_err(h[k], o[k]) <= 1e-9, (bb, k)
+
+
 @pytest.mark.parametrize("kind", ["lw", "sw"])
 @pytest.mark.parametrize("ngpt,nbnd", [(128, 16), (112, 14), (120, 6)], ids=["g128-8-per-band", "g112-8-per-band", "20-per-band"])
 def test_reduced_spectral_shapes_take_the_windowed_path(kind, ngpt, nbnd, hip_f64, oracle_f64):
