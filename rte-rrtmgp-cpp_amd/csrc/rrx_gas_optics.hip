@@ -131,14 +131,23 @@ struct InterpArgs
 };
 
 // the arithmetic of inc_2stream_by_2stream_bybnd for one g-point of a cell (rrx_misc.hip:inc_2str, same order of operations)
-template<typename F>
+// (FAST: the two divisions as Newton reciprocals -- the windowed kernel's own rounding, like its single-scattering albedo)
+template<typename F, bool FAST = false>
 __device__ __forceinline__ void add_by_band_2str(F& tau1, F& ssa1, F& g1, const F tau2, const F ssa2, const F g2)
 {
     const F eps = Lim<F>::tiny()*F(3.);
     const F tau12 = tau1 + tau2;
     const F tauscat12 = (tau1 * ssa1) + (tau2 * ssa2);
-    g1 = ((tau1 * ssa1 * g1) + (tau2 * ssa2 * g2)) / max(tauscat12, eps);
-    ssa1 = tauscat12 / max(eps, tau12);
+    if constexpr (FAST)
+    {
+        g1 = ((tau1 * ssa1 * g1) + (tau2 * ssa2 * g2)) * fast_rcp(max(tauscat12, eps));
+        ssa1 = tauscat12 * fast_rcp(max(eps, tau12));
+    }
+    else
+    {
+        g1 = ((tau1 * ssa1 * g1) + (tau2 * ssa2 * g2)) / max(tauscat12, eps);
+        ssa1 = tauscat12 / max(eps, tau12);
+    }
     tau1 = tau12;
 }
 
@@ -1241,6 +1250,9 @@ planck_fraction_kernel(
 #ifndef RRX_GW_LDSDMA
 #define RRX_GW_LDSDMA 1   // boxes staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
+#ifndef RRX_GW_FAST_BYBAND
+#define RRX_GW_FAST_BYBAND 1  // all-sky SW form: the two divisions of the by-band combination as Newton reciprocals
+#endif
 #ifndef RRX_GW_BANDCHUNKS
 #define RRX_GW_BANDCHUNKS 1   // chunks end where the flavor or the contributor set changes (0: every 16 g-points, the cut of rounds 1-3; A/B runs)
 #endif
@@ -2083,7 +2095,7 @@ gas_window_kernel(
                     if constexpr (CLD)
                     {
                         F gg = F(0.);
-                        add_by_band_2str(tt, ww, gg, c_tau, c_ssa, c_g);
+                        add_by_band_2str<F, RRX_GW_FAST_BYBAND != 0>(tt, ww, gg, c_tau, c_ssa, c_g);
                         if (active) { slab_store(tau, ig, tt); slab_store(ssa, ig, ww); slab_store(g, ig, gg); }
                     }
                     else if (active)
