@@ -54,6 +54,13 @@ int rrx_memset(void* dst, int value, unsigned long long bytes, void* stream);
 int rrx_synchronize(void* stream);
 int rrx_stream_create(void** stream);
 int rrx_stream_destroy(void* stream);
+/* The any-nlay solver forms (LW with several quadrature angles or Jacobians, columns of 288 layers and more, do_broadband outside
+   the fused tilings) keep ONE grow-only block of device memory per (calling thread, device, stream) for their per-g-point
+   temporaries. The stream owns it: rrx_stream_destroy returns it to the pool, and so does rrx_release_workspace (for streams the
+   caller created itself -- call it from the thread that made the solver calls, before destroying the stream). A block larger than
+   RRX_WORKSPACE_KEEP bytes (environment, default 32 GiB) is returned at the end of the call that used it. */
+int rrx_release_workspace(void* stream);
+unsigned long long rrx_workspace_bytes(void* stream);
 /* include/Array.h:311-350,579-622 (Array_gpu::subset / subset_kernel): N-D block gather, singleton dimensions are
    broadcast. sub_dims/strides/starts/spread are HOST arrays of length ndim (<= 7); strides in elements, starts 0-based. */
 int rrx_subset_nd(void* out, const void* in, int elem_bytes, int ndim, const int* sub_dims, const long long* strides,

@@ -162,7 +162,16 @@ namespace rrx
         const double t = fma(r*r, p, r);
         return __builtin_amdgcn_ldexp(t + 1.0, (int)n);
     }
-    __device__ __forceinline__ float exp_neg(const float x) { return exp(x); }
+    // fp32: v_exp_f32 (2^p, 1 ulp) on p = x log2(e), with the rounding error of that product and the tail of log2(e) added back
+    // to first order (exp2(p + d) = exp2(p)(1 + d ln 2)): 5 VALU + 1 transcendental instruction against the library's ~14
+    // (its range handling: x <= 0 needs none; results below FLT_MIN flush to zero).
+    __device__ __forceinline__ float exp_neg(const float x)
+    {
+        const float p = x * 0x1.715476p+0f;
+        const float d = fmaf(x, 0x1.4ae0c0p-26f, fmaf(x, 0x1.715476p+0f, -p));
+        const float y = __builtin_amdgcn_exp2f(p);
+        return fmaf(y, d * 0x1.62e430p-1f, y);
+    }
 
     // sqrt(x) for normal x well inside the exponent range (here: k^2 in [1e-12, 16]): v_rsq_f64 (2^-23) + one coupled
     // Goldschmidt step + one Newton correction, i.e. the library sequence without its scaling of tiny arguments and its
@@ -176,7 +185,8 @@ namespace rrx
         const double d = fma(-g, g, x);
         return fma(d, h, g);
     }
-    __device__ __forceinline__ float sqrt_pos(const float x) { return sqrt(x); }
+    // fp32: v_sqrt_f32 (1 ulp) without the library's scaling of denormal arguments
+    __device__ __forceinline__ float sqrt_pos(const float x) { return __builtin_amdgcn_sqrtf(x); }
 
     inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
 
@@ -197,29 +207,38 @@ namespace rrx
         if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) configured_device = dev;
     }
 
-    // Grow-only device workspace kept per (thread, device, stream) for the large per-g-point temporaries of the any-nlay solver
-    // paths (several GB each at 4 096 columns x 288 layers). Taken from the pool call by call, blocks of these sizes in changing
-    // order made hipMallocAsync go back to the driver every time (rocprofv3 --hip-trace: 90 ms per call on average, 2.1 s at most;
-    // 950 ms per step where the kernels take 25). Work on one stream is ordered, so the block can be handed out again as it is.
-    inline void* cached_workspace(hipStream_t st, const size_t bytes)
+    // Device workspace for the large per-g-point temporaries of the any-nlay solver paths (several GB each at 4 096 columns x
+    // 288 layers). Taken from the pool call by call, blocks of these sizes in changing order made hipMallocAsync go back to the
+    // driver every time (rocprofv3 --hip-trace: 90 ms per call on average, 2.1 s at most; 950 ms per step where the kernels take
+    // 25), so ONE grow-only block is kept per (calling thread, device, stream); work on a stream is ordered, so the block can be
+    // handed out again as it is. Ownership (round 4): the block belongs to the stream. It is returned to the pool by
+    // rrx_release_workspace(stream), which rrx_stream_destroy calls, and at the end of the entry point that leased it when it is
+    // larger than the retention cap (RRX_WORKSPACE_KEEP bytes in the environment, default 32 GiB). An entry point leases the
+    // block ONCE (WorkspaceLease) and carves everything it and the functions it calls need out of that one lease.
+    // Defined in rrx_misc.hip.
+    void* cached_workspace(hipStream_t st, size_t bytes);
+    void release_workspace(hipStream_t st);            // the calling thread's block for this stream goes back to the pool
+    void trim_workspace(hipStream_t st);               // ... only if it is larger than the retention cap
+    size_t workspace_bytes(hipStream_t st);            // size of the calling thread's block for this stream (0 = none)
+
+    class WorkspaceLease
     {
-        struct Slot { int dev; hipStream_t st; void* p; size_t cap; };
-        static thread_local std::vector<Slot> slots;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("workspace allocation failed");
-        Slot* slot = nullptr;
-        for (Slot& s : slots) if (s.dev == dev && s.st == st) slot = &s;
-        if (slot == nullptr) { slots.push_back(Slot{dev, st, nullptr, 0}); slot = &slots.back(); }
-        if (slot->cap < bytes)
-        {
-            if (slot->p != nullptr) (void)hipFreeAsync(slot->p, st);
-            slot->p = nullptr; slot->cap = 0;
-            keep_pool_memory();
-            if (hipMallocAsync(&slot->p, bytes, st) != hipSuccess) throw std::runtime_error("workspace allocation failed");
-            slot->cap = bytes;
-        }
-        return slot->p;
-    }
+        public:
+            explicit WorkspaceLease(hipStream_t st) : st_(st) {}
+            WorkspaceLease(const WorkspaceLease&) = delete;
+            WorkspaceLease& operator=(const WorkspaceLease&) = delete;
+            // one request per lease: a second one could move the block under the first one's pointers
+            template<typename F> F* get(const size_t n)
+            {
+                if (taken_) throw std::runtime_error("workspace leased twice in one call");
+                taken_ = true;
+                return static_cast<F*>(cached_workspace(st_, n*sizeof(F)));
+            }
+            ~WorkspaceLease() { if (taken_) trim_workspace(st_); }
+        private:
+            hipStream_t st_;
+            bool taken_ = false;
+    };
 
     // Stream-ordered scratch that is returned to the pool on every exit path (a throw after the first allocation must
     // not leak the earlier ones: a transient out-of-memory in a long-running host model would become permanent).

@@ -5,6 +5,7 @@
 // (the reference's optical-props launchers put the g-point on threadIdx.x, i.e. strided by ncol*nlay) and moves
 // 16 B per lane where the alignment allows.
 #include <mutex>
+#include <vector>
 #include <cstdlib>
 #include "rrx_common.h"
 #include "rrx_hip.h"
@@ -24,6 +25,60 @@ namespace rrx
             return d;
         }();
         return t;
+    }
+    namespace
+    {
+        struct WsSlot { int dev; hipStream_t st; void* p; size_t cap; };
+        std::vector<WsSlot>& ws_slots() { static thread_local std::vector<WsSlot> slots; return slots; }
+        size_t ws_keep_limit()
+        {
+            static const size_t limit = []
+            {
+                if (const char* e = std::getenv("RRX_WORKSPACE_KEEP")) return size_t(std::strtoull(e, nullptr, 10));
+                return size_t(32) << 30;
+            }();
+            return limit;
+        }
+        WsSlot* ws_find(hipStream_t st)
+        {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+            for (WsSlot& s : ws_slots()) if (s.dev == dev && s.st == st) return &s;
+            return nullptr;
+        }
+    }
+    void* cached_workspace(hipStream_t st, const size_t bytes)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("workspace allocation failed");
+        WsSlot* slot = ws_find(st);
+        if (slot == nullptr) { ws_slots().push_back(WsSlot{dev, st, nullptr, 0}); slot = &ws_slots().back(); }
+        if (slot->cap < bytes)
+        {
+            if (slot->p != nullptr) (void)hipFreeAsync(slot->p, st);
+            slot->p = nullptr; slot->cap = 0;
+            keep_pool_memory();
+            if (hipMallocAsync(&slot->p, bytes, st) != hipSuccess) throw std::runtime_error("workspace allocation failed");
+            slot->cap = bytes;
+        }
+        return slot->p;
+    }
+    void release_workspace(hipStream_t st)
+    {
+        WsSlot* slot = ws_find(st);
+        if (slot == nullptr) return;
+        if (slot->p != nullptr) (void)hipFreeAsync(slot->p, st);
+        ws_slots().erase(ws_slots().begin() + (slot - ws_slots().data()));
+    }
+    void trim_workspace(hipStream_t st)
+    {
+        const WsSlot* slot = ws_find(st);
+        if (slot != nullptr && slot->cap > ws_keep_limit()) release_workspace(st);
+    }
+    size_t workspace_bytes(hipStream_t st)
+    {
+        const WsSlot* slot = ws_find(st);
+        return slot ? slot->cap : 0;
     }
     int check_launch(const char* what)
     {
@@ -485,7 +540,14 @@ int rrx_memcpy_d2d(void* dst, const void* src, unsigned long long bytes, void* s
 int rrx_memset(void* dst, int value, unsigned long long bytes, void* stream) { RRX_HIP_OK(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)), "rrx_memset"); return 0; }
 int rrx_synchronize(void* stream) { RRX_HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "rrx_synchronize"); return 0; }
 int rrx_stream_create(void** stream) { hipStream_t s; RRX_HIP_OK(hipStreamCreate(&s), "rrx_stream_create"); *stream = s; return 0; }
-int rrx_stream_destroy(void* stream) { RRX_HIP_OK(hipStreamDestroy(static_cast<hipStream_t>(stream)), "rrx_stream_destroy"); return 0; }
+int rrx_stream_destroy(void* stream)
+{
+    rrx::release_workspace(static_cast<hipStream_t>(stream));       // the stream owns its workspace block (rrx_common.h)
+    RRX_HIP_OK(hipStreamDestroy(static_cast<hipStream_t>(stream)), "rrx_stream_destroy");
+    return 0;
+}
+int rrx_release_workspace(void* stream) { rrx::release_workspace(static_cast<hipStream_t>(stream)); return 0; }
+unsigned long long rrx_workspace_bytes(void* stream) { return rrx::workspace_bytes(static_cast<hipStream_t>(stream)); }
 
 #define ST static_cast<hipStream_t>(stream)
 

@@ -350,8 +350,13 @@ lw_noscat_scan_kernel(
 #endif
 // NW = wavefronts per workgroup: 4, or 8 with W = 8 for columns of up to 287 layers (round 3: eight waves x four level-lanes x
 // nine layers; one workgroup per CU then, the same two waves per SIMD).
+// Round 4, fp32: one column per lane, W = 4 and NW = 8 (two column groups per workgroup share each 128-B line of the 64-B rows),
+// compiled for four waves per SIMD -- the geometry of the fp32 SW solver (rrx_solver_sw.hip, CLT note).
+#ifndef RRX_LW_F32_WAVES
+#define RRX_LW_F32_WAVES 2
+#endif
 template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = RRX_LW_EV, int NW = (W > 4 ? W : 4)>
-__global__ void __launch_bounds__(64*NW, NW > 4 ? 1 : 2)
+__global__ void __launch_bounds__(64*NW, (NW > W) ? (NW >= 12 ? NW/4 : RRX_LW_F32_WAVES) : (NW > 4 ? 1 : 2))
 lw_noscat_bb_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ secants, const F* __restrict__ weights,
@@ -806,7 +811,7 @@ bool launch_scan_bb16(
 
 
 // second-generation fused broadband kernel (lw_noscat_bb_kernel); LITE: lay_source = pfrac, lev_source unused
-template<typename F, int V, int W, int CLT, bool LITE>
+template<typename F, int V, int W, int CLT, bool LITE, int NW = (W > 4 ? W : 4)>
 bool launch_bb2(
         hipStream_t st, const bool pre, const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* secants, const F* weights, const F* tau, const F* lay_source, const F* lev_source,
@@ -814,10 +819,9 @@ bool launch_bb2(
         const F* sfc_emis, const F* sfc_src, const F* inc_flux, F* flux_up, F* flux_dn)
 {
     if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
-    constexpr int NW = (W > 4) ? W : 4;
     const int groups = ceil_div(ncol, (NW/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
-    if (need > ((CLT == 16) ? 9 : 5)) return false;
+    if (need > ((CLT == 16) ? ((NW > W && W == 6) ? 6 : ((NW > W && W == 8) ? 5 : 9)) : 5)) return false;
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
@@ -827,17 +831,19 @@ bool launch_bb2(
     if (nsplit > 1) { out_up = scratch.get<F>(2*nsplit*nlevcol); out_dn = out_up + nsplit*nlevcol; }
     const dim3 grid(groups, nsplit);
 #define RRX_LW_B2(KK) if (need <= KK) { \
-        if (nsplit > 1 && pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        if (nsplit > 1 && pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,true,RRX_LW_EV,NW><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else if (nsplit > 1) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else if (nsplit > 1) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,true,RRX_LW_EV,NW><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else if (pre) lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,true,false,RRX_LW_EV,NW><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
-        else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
+        else lw_noscat_bb_kernel<F,V,KK,W,CLT,LITE,false,false,RRX_LW_EV,NW><<<grid, 64*NW, 0, st>>>(ncol, nlay, ngpt, top_at_1, secants, weights, tau, \
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
         break; }
     do {
-    if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
+    if constexpr (CLT == 16 && W == 6 && NW > W) { RRX_LW_B2(6) }
+    else if constexpr (CLT == 16 && W == 8 && NW > W) { RRX_LW_B2(5) }
+    else if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
     else                     { RRX_LW_B2(2) RRX_LW_B2(3) RRX_LW_B2(5) }
     } while (false);
     if (nsplit > 1)
@@ -874,6 +880,19 @@ bool lw_fused_broadband(
     }
     else
     {
+        // one column per lane, two column groups per workgroup, four waves per SIMD (variant 15 = the forms of rounds 1-3)
+        if (tuning().lw_variant == 16 &&      // A/B: six waves x six layers, one 768-thread workgroup per CU, three waves per SIMD
+            launch_bb2<F,1,6,16,LITE,12>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        if (tuning().lw_variant == 17 &&      // A/B: eight waves x five layers, one 1024-thread workgroup per CU, four waves per SIMD
+            launch_bb2<F,1,8,16,LITE,16>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        if (tuning().lw_variant != 15 &&
+            launch_bb2<F,1,4,16,LITE,8>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
         if (ncol % 2 == 0 && v2_first &&
             launch_bb2<F,2,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
@@ -907,7 +926,7 @@ int lw_solver_noscat_impl(
         F* flux_up, F* flux_dn,
         const Bool do_broadband, F* flux_up_loc, F* flux_dn_loc,
         const Bool do_jacobians, const F* sfc_src_jac, F* flux_up_jac,
-        void* stream)
+        void* stream, F* flux_ws = nullptr /* room for 2*ncol*(nlay+1)*ngpt values out of the CALLER's workspace lease, or null */)
 {
     RRX_TRY
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -921,8 +940,8 @@ int lw_solver_noscat_impl(
     // to fill the chip one workgroup sums all g-points in order (sum_broadband's order); with fewer the g-point range is split
     // over grid.y and the partial sums are added in range order (rrx::broadband_gsplit).
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
-    const bool second_gen = (g_lw_variant == 0 || g_lw_variant == 13 || g_lw_variant == 14);        // splits its g-point loop when columns are few
-    if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && ncol % VBB == 0
+    const bool second_gen = (g_lw_variant == 0 || (g_lw_variant >= 13 && g_lw_variant <= 17));        // splits its g-point loop when columns are few
+    if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && (ncol % VBB == 0 || (second_gen && sizeof(F) == 4))
         && (second_gen || ceil_div(ncol, CL*VBB) >= g_bb_min_groups))
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
@@ -933,7 +952,7 @@ int lw_solver_noscat_impl(
                                         flux_up_loc, flux_dn_loc))
             return 0;
         // the first-generation tilings do not split the g-point loop: only with enough column groups
-        if (ceil_div(ncol, CL*VBB) >= g_bb_min_groups) {
+        if (ncol % VBB == 0 && ceil_div(ncol, CL*VBB) >= g_bb_min_groups) {
         // four waves per column group (K = 5 at 140 layers) leave room for the g-point sums AND 128-B row segments.
         // Measured at C4: fp32 2.15 ms against 2.28 ms with two waves / 64-B rows; fp64 3.94 against 3.15 ms (256 VGPRs,
         // 12 % idle level-lanes), so fp64 keeps two waves unless variant 9 asks for four.
@@ -956,12 +975,12 @@ int lw_solver_noscat_impl(
 
     // broadband mode, general form: per-g-point fluxes go to a workspace, then are summed over g-points
     F* up = flux_up; F* dn = flux_dn;
-    StreamScratch scratch(st);
+    WorkspaceLease lease(st);
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     if (do_broadband)
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("do_broadband needs flux_*_loc");
-        F* ws = static_cast<F*>(cached_workspace(st, 2*nlevcol*ngpt*sizeof(F)));      // (first in the stream's cached block)
+        F* ws = (flux_ws != nullptr) ? flux_ws : lease.get<F>(2*nlevcol*ngpt);
         up = ws; dn = ws + nlevcol*ngpt;
     }
 
@@ -1055,23 +1074,26 @@ int lw_solver_noscat_fractions_impl(
         if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
         const int var = tuning().lw_variant;
-        if ((var == 0 || var == 13 || var == 14) &&
+        if ((var == 0 || (var >= 13 && var <= 17)) &&
             lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return check_launch("rrx_lw_solver_noscat_fractions");
         } catch (const std::exception& e) { rrx::set_error(std::string("rrx_lw_solver_noscat_fractions: ") + e.what()); return 1; }
     }
-    // outside the one-kernel form (few columns, very tall columns, A/B variants): rebuild the sources and take the general entry
-    // (the two source arrays sit behind the room the general entry takes for its per-g-point fluxes in the same cached block)
-    F* lay = nullptr; F* lev = nullptr;
+    // outside the one-kernel form (few columns, very tall columns, A/B variants): rebuild the sources and take the general entry.
+    // ONE lease of the stream's workspace, carved here: [per-g-point fluxes of the general entry: 2 n_lev | lay_source | lev_source];
+    // the general entry is handed its part explicitly.
     const size_t n_lay = size_t(ncol)*nlay*ngpt, n_lev = size_t(ncol)*(nlay+1)*ngpt;
-    try { lay = static_cast<F*>(cached_workspace(st, (2*n_lev + n_lay + n_lev)*sizeof(F))) + 2*n_lev; }
+    WorkspaceLease lease(st);
+    F* flux_ws = nullptr;
+    try { flux_ws = lease.get<F>(2*n_lev + n_lay + n_lev); }
     catch (const std::exception& e) { rrx::set_error(std::string("rrx_lw_solver_noscat_fractions: ") + e.what()); return 1; }
-    lev = lay + n_lay;
+    F* lay = flux_ws + 2*n_lev; F* lev = lay + n_lay;
     int rc = planck_sources_from_fractions_impl<F>(ncol, nlay, ngpt, gpoint_bands, pfrac, blay, blev, lay, lev, stream);
     if (rc == 0)
         rc = lw_solver_noscat_impl<F>(ncol, nlay, ngpt, top_at_1, 1, secants, weights, tau, lay, lev, sfc_emis, sfc_src, inc_flux,
-                                      (F*)nullptr, (F*)nullptr, Bool(1), flux_up_loc, flux_dn_loc, Bool(0), (const F*)nullptr, (F*)nullptr, stream);
+                                      (F*)nullptr, (F*)nullptr, Bool(1), flux_up_loc, flux_dn_loc, Bool(0), (const F*)nullptr, (F*)nullptr, stream,
+                                      flux_ws);
     return rc;
 }
 }  // namespace

@@ -14,6 +14,7 @@
 // Inside a lane the K layers are always replayed with the reference's own formulas.
 #include "rrx_common.h"
 #include "rrx_hip.h"
+#include <type_traits>
 
 #pragma clang fp contract(fast)
 
@@ -37,6 +38,9 @@ constexpr int BB_EVALS = RRX_SW_BB_EVALS;   // fused broadband form: two_stream 
 #endif
 #ifndef RRX_SW_MINWAVES2
 #define RRX_SW_MINWAVES2 2
+#endif
+#ifndef RRX_SW_F32_WAVES
+#define RRX_SW_F32_WAVES 2    // waves per SIMD the fp32 geometry (16 x 4 lanes, one column per lane) is compiled for
 #endif
 
 template<typename F>
@@ -111,8 +115,13 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // W = 4 (round 3): four wavefronts per column group, eight per workgroup (two column groups, as with W = 2): columns of up to 287
 // layers at nine layers per lane; the wave totals of a scan are then combined over the group's waves in order (the W = 2 code is
 // the two-wave case of the same composition, kept as it was).
-template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false, int NW = (W > 2 ? 2*W : 4)>
-__global__ void __launch_bounds__(64*NW, (NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES))
+// CLT = column lanes per wavefront (level lanes = 64 / CLT). 8 x 8 is the fp64 geometry (64-B rows per wave, two column groups per
+// workgroup share each 128-B line). Round 4, fp32: 16 x 4 lanes with ONE column per lane, four waves per column group and two groups
+// per workgroup -- the same nine cells per lane and the same 64-B rows as fp64, half the registers: four waves per SIMD, which is
+// where the fp32 pipe issues an instruction every 2.0 cycles (3.5 at two waves; packed v_pk_fma_f32 costs 3.8 whatever the
+// occupancy, profiles/r04_fp32_issue_costs.txt, so two columns per lane on packed math buy nothing).
+template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false, int NW = (W > 2 ? 2*W : 4), int CLT = 8>
+__global__ void __launch_bounds__(64*NW, (CLT == 16) ? (NW >= 12 ? NW/4 : (K <= 9 ? RRX_SW_F32_WAVES : 2)) : ((NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)))
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
@@ -120,6 +129,7 @@ sw_2stream_scan_kernel(
         const F* __restrict__ inc_flux_dir, const F* __restrict__ inc_flux_dif,
         F* __restrict__ flux_up, F* __restrict__ flux_dn, F* __restrict__ flux_dir, const int sync_waves, const int gper)
 {
+    constexpr int CL = CLT, LL = 64/CLT;              // shadow the default geometry
     // per-thread private LDS columns (dynamic register indexing is not needed: j is a compile-time constant, but
     // two of the six per-layer arrays live here so that the kernel fits 2 waves per SIMD)
     __shared__ F lds_alb[K*V][64*NW];
@@ -132,7 +142,7 @@ sw_2stream_scan_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cl = lane & (CL-1);
-    const int ll = lane >> 3;
+    const int ll = lane / CL;
     const int h = (W >= 2) ? (wave % W) : 0;          // which part of the column this wave holds (0 = TOA side)
     [[maybe_unused]] const int w0 = wave - h;         // first wave of the column group
     const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
@@ -172,14 +182,21 @@ sw_2stream_scan_kernel(
         const int ml = top_at_1 ? min(t0 + j, nlay-1) : max(nlay-1-t0-j, 0);
         return unsigned(ml)*unsigned(ncol) + unsigned(icol);
     };
-    Vec<F,V> nt[PRE ? K : 1], nw[PRE ? K : 1], n_inc, n_adir, n_adif;
+    Vec<F,V> nt[PRE ? K : 1], nw[PRE ? K : 1], ng[(PRE && !GZ) ? K : 1], n_inc, n_adir, n_adif;
     if constexpr (PRE)
     {
-        static_assert(BB && GZ && W >= 2, "the pipelined form is the fused broadband kernel without g array");
+        static_assert(BB && W >= 2, "the pipelined form is the fused broadband kernel");
+        static_assert(GZ || sizeof(F) == 4, "fp64 with a g array: 27 prefetched doubles per lane spill (5.8 -> 7.2 ms, round 3)");
         const F* __restrict__ tau_0 = tau + size_t(g_begin)*ncl*nlay;
         const F* __restrict__ ssa_0 = ssa + size_t(g_begin)*ncl*nlay;
         #pragma unroll
         for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau_0 + o); nw[j] = load_cols<F,V>(ssa_0 + o); }
+        if constexpr (!GZ)
+        {
+            const F* __restrict__ g_0 = g + size_t(g_begin)*ncl*nlay;
+            #pragma unroll
+            for (int j=0; j<K; ++j) ng[j] = load_cols<F,V>(g_0 + off_of(j));
+        }
         const size_t s0 = size_t(g_begin)*ncl + icol;
         n_inc = load_cols<F,V>(inc_flux_dir + s0); n_adir = load_cols<F,V>(sfc_alb_dir + s0); n_adif = load_cols<F,V>(sfc_alb_dif + s0);
     }
@@ -215,8 +232,12 @@ sw_2stream_scan_kernel(
         if constexpr (PRE)
         {
             tv = nt[j]; wv = nw[j];
-            #pragma unroll
-            for (int v=0; v<V; ++v) gv.v[v] = F(0.);
+            if constexpr (GZ)
+            {
+                #pragma unroll
+                for (int v=0; v<V; ++v) gv.v[v] = F(0.);
+            }
+            else gv = ng[j];
         }
         else
         {
@@ -327,6 +348,12 @@ sw_2stream_scan_kernel(
                     const F* __restrict__ ssa_n = ssa + size_t(gn)*ncl*nlay;
                     #pragma unroll
                     for (int j=0; j<K; ++j) { const unsigned o = off_of(j); nt[j] = load_cols<F,V>(tau_n + o); nw[j] = load_cols<F,V>(ssa_n + o); }
+                    if constexpr (!GZ)
+                    {
+                        const F* __restrict__ g_n = g + size_t(gn)*ncl*nlay;
+                        #pragma unroll
+                        for (int j=0; j<K; ++j) ng[j] = load_cols<F,V>(g_n + off_of(j));
+                    }
                     const size_t sn = size_t(gn)*ncl + icol;
                     n_inc = load_cols<F,V>(inc_flux_dir + sn); n_adir = load_cols<F,V>(sfc_alb_dir + sn); n_adif = load_cols<F,V>(sfc_alb_dif + sn);
                     __builtin_amdgcn_sched_barrier(0);
@@ -704,18 +731,26 @@ bool launch_scan(hipStream_t st,
     return false;
 }
 
-template<typename F, int V, int W = 2>
+// run f with a compile-time copy of a run-time flag
+template<typename Fn> void with_flag(const bool flag, Fn&& f) { if (flag) f(std::true_type{}); else f(std::false_type{}); }
+
+// Fused broadband form. W waves per column group, CLT column lanes per wave (two column groups per workgroup); false when the
+// columns are taller than the form's largest K (the caller tries the next form).
+template<typename F, int V, int W = 2, int CLT = 8>
 bool launch_scan_bb(hipStream_t st,
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
     constexpr int NW = (W > 2) ? 2*W : 4;                 // wavefronts per workgroup: two column groups
-    const int groups = ceil_div(ncol, 2*CL*V);
-    const int need = ceil_div(nlay+1, LL*W);
-    if (need > (W > 2 ? 9 : 12)) return false;            // (W = 4: nine layers per lane fill the LDS of a CU)
-    // (fp32, two columns per lane: the pipelined form needs 140 B of scratch per lane and is slower, 4.00 against 3.63 ms at C4)
-    const bool pre = sizeof(F) == 8 && tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31);
+    constexpr int KMAX = (CLT == 16) ? (W == 6 ? 6 : (W == 8 ? 5 : 12)) : (W > 2 ? 9 : 12);       // (8 x 8 lanes, W = 4: nine layers per lane fill the LDS of a CU)
+    const int groups = ceil_div(ncol, 2*CLT*V);
+    const int need = ceil_div(nlay+1, (64/CLT)*W);
+    if (need > KMAX) return false;
+    // pipelined loads: fp64 without g array only (with it 27 prefetched doubles spill); fp32 in the one-column-per-lane geometry
+    // (two columns per lane: 140 B of scratch per lane, 4.00 against 3.63 ms at C4)
+    const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31)
+                     && (sizeof(F) == 8 ? g == nullptr : (V == 1 && CLT == 16));
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
@@ -724,27 +759,28 @@ bool launch_scan_bb(hipStream_t st,
     F* up = flux_up; F* dn = flux_dn; F* dr = flux_dir;
     if (nsplit > 1) { up = scratch.get<F>(3*nsplit*nlevcol); dn = up + nsplit*nlevcol; dr = dn + nsplit*nlevcol; }
     const dim3 grid(groups, nsplit);
-#define RRX_SW_K(KK) if (need <= KK) { \
-        if (nsplit > 1 && g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,W,true,true,true,true><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        else if (nsplit > 1 && g == nullptr) sw_2stream_scan_kernel<F,V,KK,W,true,true,false,true><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        else if (nsplit > 1) sw_2stream_scan_kernel<F,V,KK,W,true,false,false,true><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        else if (g == nullptr && pre) sw_2stream_scan_kernel<F,V,KK,W,true,true,true><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        else if (g == nullptr) sw_2stream_scan_kernel<F,V,KK,W,true,true><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        else sw_2stream_scan_kernel<F,V,KK,W,true,false><<<grid, 64*NW, 0, st>>>( \
-            ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif, \
-            up, dn, dr, tuning().sync_waves, gper); \
-        break; }
-    do { if constexpr (W == 2) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) } else { RRX_SW_K(9) } } while (false);
+    const int sync_waves = tuning().sync_waves;
+    auto launch = [&](auto kk)
+    {
+        constexpr int KK = decltype(kk)::value;
+        with_flag(g == nullptr, [&](auto gz) { with_flag(pre, [&](auto pr) { with_flag(nsplit > 1, [&](auto gs)
+        {
+            constexpr bool GZ = decltype(gz)::value, GS = decltype(gs)::value;
+            constexpr bool PRE = decltype(pr)::value && (GZ || sizeof(F) == 4);
+            sw_2stream_scan_kernel<F,V,KK,W,true,GZ,PRE,GS,NW,CLT><<<grid, 64*NW, 0, st>>>(
+                ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif,
+                up, dn, dr, sync_waves, gper);
+        }); }); });
+    };
+#define RRX_SW_K(KK) if (need <= KK) { launch(std::integral_constant<int,KK>{}); break; }
+    do
+    {
+        if constexpr (CLT == 16 && W == 6) { RRX_SW_K(6) }
+        else if constexpr (CLT == 16 && W == 8) { RRX_SW_K(5) }
+        else if constexpr (CLT == 16) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
+        else if constexpr (W == 2) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
+        else { RRX_SW_K(9) }
+    } while (false);
 #undef RRX_SW_K
     if (nsplit > 1)
     {
@@ -777,15 +813,34 @@ int sw_solver_2stream_impl(
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
     (void)g_bb_min_groups;
     // (variant 8: fused broadband form without the pipelined loads, for A/B runs)
-    if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && ncol % VBB == 0)
+    if (do_broadband && g_sw_variant != 1 && g_sw_variant != 7 && (ncol % VBB == 0 || sizeof(F) == 4))
     {
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr || flux_dir_loc == nullptr)
             throw std::runtime_error("do_broadband needs flux_*_loc");
-        if (launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+        // fp32: one column per lane, 16 x 4 lanes, four waves per column group (up to 191 layers); variant 9 = the two-columns-
+        // per-lane form of rounds 1-3 for A/B runs
+        if constexpr (sizeof(F) == 4)
+        {
+            if (g_sw_variant == 10 &&       // A/B: six waves x six layers, one 768-thread workgroup per CU, three waves per SIMD
+                launch_scan_bb<F,1,6,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                         inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+                return 0;
+            if (g_sw_variant == 11 &&       // A/B: eight waves x five layers, one 1024-thread workgroup per CU, four waves per SIMD
+                launch_scan_bb<F,1,8,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                         inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+                return 0;
+            if (g_sw_variant != 9 &&
+                launch_scan_bb<F,1,4,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                         inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+                return 0;
+        }
+        if (ncol % VBB == 0 &&
+            launch_scan_bb<F,VBB>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                   inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
         // 192 ... 287 layers: four wavefronts per column group
-        if (launch_scan_bb<F,VBB,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+        if (ncol % VBB == 0 &&
+            launch_scan_bb<F,VBB,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                     inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
     }
@@ -796,7 +851,10 @@ int sw_solver_2stream_impl(
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     const size_t w_g = (g == nullptr) ? size_t(ncol)*nlay*ngpt : 0, w_flux = do_broadband ? 3*nlevcol*ngpt : 0;
     const size_t w_serial = 5*size_t(ncol)*nlay*ngpt + 2*nlevcol*ngpt;
-    F* big = (w_g + w_flux > 0) ? static_cast<F*>(cached_workspace(st, (w_g + w_flux + w_serial)*sizeof(F))) : nullptr;
+    // (one lease per call: the serial kernel's part is asked for up front whenever it could be needed)
+    WorkspaceLease lease(st);
+    const bool may_go_serial = g_sw_variant == 1 || (g_sw_variant != 2 ? ceil_div(nlay+1, LL*2) > 17 : ceil_div(nlay+1, LL) > 33);   // (largest K of launch_scan)
+    F* big = (w_g + w_flux > 0 || may_go_serial) ? lease.get<F>(w_g + w_flux + (may_go_serial ? w_serial : 0)) : nullptr;
     if (g == nullptr)
     {
         if (hipMemsetAsync(big, 0, w_g*sizeof(F), st) != hipSuccess) throw std::runtime_error("workspace memset failed");
@@ -830,7 +888,8 @@ int sw_solver_2stream_impl(
     }
     if (!done)
     {
-        F* ws2 = (big != nullptr) ? big + w_g + w_flux : static_cast<F*>(cached_workspace(st, w_serial*sizeof(F)));
+        if (!may_go_serial) throw std::runtime_error("internal: no tiling for this shape and no workspace for the serial form");
+        F* ws2 = big + w_g + w_flux;
         const dim3 grid(ceil_div(ncol, 256), ngpt);
         sw_2stream_serial_kernel<F><<<grid, 256, 0, st>>>(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0,
                 sfc_alb_dir, sfc_alb_dif, inc_flux_dir, dif, up, dn, dr, ws2);

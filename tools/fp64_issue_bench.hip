@@ -10,7 +10,7 @@
 
 constexpr int ITERS = 2048;
 
-enum Op { FMA_IND, FMA_DEP, ADD_IND, MUL_IND, RCP, RSQ, LDEXP, RNDNE, CVT_I32, CVT_F32, FMA32_IND, BPERM, DPP_MOV, PLANE16, PLANE32, MAXF, CNDMASK, SQRT_LIB, EXP_LEAN, MINMAX3 };
+enum Op { FMA_IND, FMA_DEP, ADD_IND, MUL_IND, RCP, RSQ, LDEXP, RNDNE, CVT_I32, CVT_F32, FMA32_IND, BPERM, DPP_MOV, PLANE16, PLANE32, MAXF, CNDMASK, SQRT_LIB, EXP_LEAN, MINMAX3, PKFMA32, PKMUL32, PKADD32, EXP32, RCP32, RSQ32, SQRT32, MAX32, CND32, FMA32_DEP, PKFMA32_DEP };
 
 template<int OP>
 __global__ void __launch_bounds__(256) probe(double* out, unsigned long long* ticks, const double seed)
@@ -20,6 +20,9 @@ __global__ void __launch_bounds__(256) probe(double* out, unsigned long long* ti
     const double m = 1.0000001, c = 1e-9;
     float f0 = float(a0), f1 = float(a1), f2 = float(a2), f3 = float(a3), f4 = float(a4), f5 = float(a5), f6 = float(a6), f7 = float(a7);
     int i0 = lane, i1 = lane + 1, i2 = lane + 2, i3 = lane + 3;
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    pf2 p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f4, f5}, p3 = {f6, f7}, p4 = {f1, f0}, p5 = {f3, f2}, p6 = {f5, f4}, p7 = {f7, f6};
+    const pf2 pm = {1.0000001f, 0.9999999f}, pc = {1e-9f, 2e-9f};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     #pragma unroll 1
@@ -80,9 +83,23 @@ __global__ void __launch_bounds__(256) probe(double* out, unsigned long long* ti
                                       asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
         if constexpr (OP == SQRT_LIB) { a0 = sqrt(a0) + 2; a1 = sqrt(a1) + 2; a2 = sqrt(a2) + 2; a3 = sqrt(a3) + 2; a4 = sqrt(a4) + 2; a5 = sqrt(a5) + 2; a6 = sqrt(a6) + 2; a7 = sqrt(a7) + 2; }
         if constexpr (OP == EXP_LEAN) { a0 = exp(-a0) + 1; a1 = exp(-a1) + 1; a2 = exp(-a2) + 1; a3 = exp(-a3) + 1; a4 = exp(-a4) + 1; a5 = exp(-a5) + 1; a6 = exp(-a6) + 1; a7 = exp(-a7) + 1; }
+        // round 4: the fp32 instructions the packed (two columns per lane) solvers are made of
+        if constexpr (OP == PKFMA32) { p0 = __builtin_elementwise_fma(p0, pm, pc); p1 = __builtin_elementwise_fma(p1, pm, pc); p2 = __builtin_elementwise_fma(p2, pm, pc); p3 = __builtin_elementwise_fma(p3, pm, pc); p4 = __builtin_elementwise_fma(p4, pm, pc); p5 = __builtin_elementwise_fma(p5, pm, pc); p6 = __builtin_elementwise_fma(p6, pm, pc); p7 = __builtin_elementwise_fma(p7, pm, pc); }
+        if constexpr (OP == PKFMA32_DEP) { p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); p0 = __builtin_elementwise_fma(p0, pm, pc); }
+        if constexpr (OP == FMA32_DEP) { f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); f0 = fmaf(f0, 1.0000001f, 1e-9f); }
+        if constexpr (OP == PKMUL32) { p0 *= pm; p1 *= pm; p2 *= pm; p3 *= pm; p4 *= pm; p5 *= pm; p6 *= pm; p7 *= pm; }
+        if constexpr (OP == PKADD32) { p0 += pc; p1 += pc; p2 += pc; p3 += pc; p4 += pc; p5 += pc; p6 += pc; p7 += pc; }
+        if constexpr (OP == EXP32) { f0 = __builtin_amdgcn_exp2f(f0); f1 = __builtin_amdgcn_exp2f(f1); f2 = __builtin_amdgcn_exp2f(f2); f3 = __builtin_amdgcn_exp2f(f3); f4 = __builtin_amdgcn_exp2f(f4); f5 = __builtin_amdgcn_exp2f(f5); f6 = __builtin_amdgcn_exp2f(f6); f7 = __builtin_amdgcn_exp2f(f7); }
+        if constexpr (OP == RCP32) { f0 = __builtin_amdgcn_rcpf(f0); f1 = __builtin_amdgcn_rcpf(f1); f2 = __builtin_amdgcn_rcpf(f2); f3 = __builtin_amdgcn_rcpf(f3); f4 = __builtin_amdgcn_rcpf(f4); f5 = __builtin_amdgcn_rcpf(f5); f6 = __builtin_amdgcn_rcpf(f6); f7 = __builtin_amdgcn_rcpf(f7); }
+        if constexpr (OP == RSQ32) { f0 = __builtin_amdgcn_rsqf(f0); f1 = __builtin_amdgcn_rsqf(f1); f2 = __builtin_amdgcn_rsqf(f2); f3 = __builtin_amdgcn_rsqf(f3); f4 = __builtin_amdgcn_rsqf(f4); f5 = __builtin_amdgcn_rsqf(f5); f6 = __builtin_amdgcn_rsqf(f6); f7 = __builtin_amdgcn_rsqf(f7); }
+        if constexpr (OP == SQRT32) { f0 = __builtin_amdgcn_sqrtf(f0); f1 = __builtin_amdgcn_sqrtf(f1); f2 = __builtin_amdgcn_sqrtf(f2); f3 = __builtin_amdgcn_sqrtf(f3); f4 = __builtin_amdgcn_sqrtf(f4); f5 = __builtin_amdgcn_sqrtf(f5); f6 = __builtin_amdgcn_sqrtf(f6); f7 = __builtin_amdgcn_sqrtf(f7); }
+        if constexpr (OP == MAX32) { f0 = fmaxf(f0, 1e-9f); f1 = fmaxf(f1, 1e-9f); f2 = fmaxf(f2, 1e-9f); f3 = fmaxf(f3, 1e-9f); f4 = fmaxf(f4, 1e-9f); f5 = fmaxf(f5, 1e-9f); f6 = fmaxf(f6, 1e-9f); f7 = fmaxf(f7, 1e-9f);
+                                    asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)); }
+        if constexpr (OP == CND32) { f0 = (i0 & 1) ? f0 : f1; f2 = (i0 & 1) ? f2 : f3; f4 = (i0 & 1) ? f4 : f5; f6 = (i0 & 1) ? f6 : f7; f1 = (i0 & 1) ? f1 : f2; f3 = (i0 & 1) ? f3 : f4; f5 = (i0 & 1) ? f5 : f6; f7 = (i0 & 1) ? f7 : f0;
+                                    asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)); }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x*blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + i0 + i1 + i2 + i3;
+    out[blockIdx.x*blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1] + p4[0] + p4[1] + p5[0] + p5[1] + p6[0] + p6[1] + p7[0] + p7[1] + i0 + i1 + i2 + i3;
     if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
@@ -128,5 +145,16 @@ int main()
     run<PLANE32>("permlane32", out, ticks, 0);
     run<SQRT_LIB>("sqrt_lib+add", out, ticks, 0);
     run<EXP_LEAN>("exp_lib+add", out, ticks, 0);
+    run<FMA32_DEP>("fma32_dep", out, ticks, 0);
+    run<PKFMA32>("pk_fma32", out, ticks, 0);
+    run<PKFMA32_DEP>("pk_fma32_dep", out, ticks, 0);
+    run<PKMUL32>("pk_mul32", out, ticks, 0);
+    run<PKADD32>("pk_add32", out, ticks, 0);
+    run<EXP32>("exp32", out, ticks, 0);
+    run<RCP32>("rcp32", out, ticks, 0);
+    run<RSQ32>("rsq32", out, ticks, 0);
+    run<SQRT32>("sqrt32", out, ticks, 0);
+    run<MAX32>("max32", out, ticks, 0);
+    run<CND32>("cndmask32", out, ticks, 0);
     return 0;
 }
