@@ -192,10 +192,9 @@ def local_atmosphere(args, nbnd, rank, world):
     from rte_rrtmgp_cpp_amd import synthetic, sharding
     ntot = global_columns(args, world)
     s, e = sharding.column_range(rank, world, ntot)
-    if getattr(args, "allsky", False):     # the all-sky atmosphere (cloud mask) is built as a whole and sharded: see main()
-        return (s, e), None
-    # only this rank's columns are built (column c is the same column whatever the number of ranks)
-    atm = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e), top_at_1=getattr(args, "top_at_1", False))
+    # only this rank's columns are built (column c is the same column whatever the number of ranks), clouds included
+    atm = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, e), top_at_1=getattr(args, "top_at_1", False),
+                                    clouds=getattr(args, "allsky", False))
     if getattr(args, "col_spread", 0.0) > 0:
         atm = spread_columns(atm, args.col_spread, s, e, ntot)
     return (s, e), atm
@@ -297,11 +296,6 @@ def main():
     (col_s, col_e), atm0 = local_atmosphere(args, nbnd, rank, world)
     cloud_luts = None
     if args.allsky:
-        from rte_rrtmgp_cpp_amd import sharding as _sh
-        full = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, clouds=True)
-        if args.col_spread > 0:
-            full = spread_columns(full, args.col_spread, 0, ntot, ntot)
-        atm0 = full if world == 1 else _sh.shard_atmosphere(full, rank, world)
         cast = lambda lut: be.upload_lut({k: (v.astype(np_dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
         cloud_luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
     ncol_local = col_e - col_s

@@ -353,6 +353,8 @@ int rrx_expand_and_transpose##SFX(int ncol, int nbnd, const int* band_lims_gpt, 
 int rrx_spread_col##SFX(int ncol, int ngpt, F* toa_src, const F* solar_source, void* stream); \
 /* src_test/Radiation_solver.cu scaling_to_subset: toa_src(icol,igpt) *= tsi_scaling(icol) */ \
 int rrx_scaling_to_subset##SFX(int ncol, int ngpt, F* toa_src, const F* tsi_scaling, void* stream); \
+/* the two above in one pass: toa_src(icol,igpt) = solar_source(igpt) * tsi_scaling(icol) (tsi_scaling = NULL: no scaling) */ \
+int rrx_toa_source##SFX(int ncol, int ngpt, F* toa_src, const F* solar_source, const F* tsi_scaling, void* stream); \
 /* src_cuda/Aerosol_optics.cu:36-263 + Aerosol_optics_gpu::aerosol_optics (:305-345): CAMS aerosol optics per band in one kernel. \
    aermr: HOST array of 11 device pointers (aermr01..aermr11), each (ncol,nlay) or, where aermr_per_column[a] == 0, one (nlay) \
    profile shared by all columns (the reference materialises the broadcast, fill_aerosols_3d); aermr_per_column may be NULL \

@@ -1287,7 +1287,7 @@ inline int gas_window_geometry(const int ncol)
 inline dim3 gather_grid(const int entries_)
 {
     const int entries = entries_*GSH;
-    static const int cap = std::getenv("RRX_GATHER_GRID") ? std::max(1, std::atoi(std::getenv("RRX_GATHER_GRID"))) : 2048;   // (A/B runs)
+    static const int cap = std::getenv("RRX_GATHER_GRID") ? std::max(1, std::atoi(std::getenv("RRX_GATHER_GRID"))) : 512;   // (A/B runs; 512 = the two workgroups per CU the kernels fit: the entries are taken from a counter anyway, and the usual launch -- nothing handed back -- costs 3 instead of 13 us)
     return dim3(std::min(entries, cap));
 }
 inline dim3 gas_window_grid(const int geom, const int ncol, const int nlay)
@@ -1351,8 +1351,14 @@ struct GasWindowTables
 };
 inline int gas_window_ncmax(const int ngpt, const int nband) { return (ngpt + GCH - 1) / GCH + std::max(nband, 0); }
 
-// The tables depend on the k-distribution alone. One small workgroup builds them per launch; the 9 000 workgroups of the windowed
+// The tables depend on the k-distribution alone. One small workgroup builds them; the 9 000 workgroups of the windowed
 // kernel copy a few KB instead of each walking the contributor arrays (set-up 0.40 -> 0.30 of 3.5 ms at C4).
+// Round 4: the buffer persists between launches (gas_window_tables below). The kernel reads the index arrays it depends on (as
+// before), compares them and the shape with what the buffer was built from -- both are part of the tables -- and leaves when
+// nothing changed: 39 -> 5 us per launch, which was 4 % of a step at 2 048 columns per GPU. A k-distribution that changed in
+// place, or another one at the same addresses, is rebuilt: the check is on the contents, not on the pointers.
+constexpr int GW_TBL_HEADER = 8;                 // ints behind the tables: magic, ngpt, nminorlower, nminorupper, ncmax, nlist
+constexpr int GW_TBL_MAGIC = 0x52525834;
 __global__ void __launch_bounds__(256)
 gas_window_tables_kernel(
         const int ngpt, const int nminorlower, const int nminorupper, const int ncmax, const int nlist,
@@ -1398,6 +1404,16 @@ gas_window_tables_kernel(
         }
     }
     __syncthreads();
+    // ---- built from the same inputs before? (flavors and contributor metadata sit in the tables as they were read)
+    {
+        int* head = tbl + ntab;
+        int differs = (head[0] != GW_TBL_MAGIC || head[1] != ngpt || head[2] != nminorlower || head[3] != nminorupper
+                       || head[4] != ncmax || head[5] != nlist) ? 1 : 0;
+        for (int w = tid; w < 2*ngpt && !differs; w += 256) differs = (tbl[w] != gflav[w]) ? 1 : 0;
+        for (int w = tid; w < 2*MM*nmax && !differs; w += 256) differs = (tbl[T.off_mmeta() + w] != mmeta[w]) ? 1 : 0;
+        if (!__syncthreads_or(differs)) return;
+        if (tid == 0) head[0] = 0;                         // (not valid while it is being rewritten)
+    }
     // ---- where chunks must start: a flavor change in either regime, the first g-point of a contributor's interval, the g-point
     // behind its last
     for (int g = tid; g < ngpt; g += 256)
@@ -1507,6 +1523,38 @@ gas_window_tables_kernel(
     }
 #endif
     for (int w = tid; w < ntab; w += 256) tbl[w] = lds_int[w];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+    {
+        int* head = tbl + ntab;
+        head[1] = ngpt; head[2] = nminorlower; head[3] = nminorupper; head[4] = ncmax; head[5] = nlist;
+        __threadfence();
+        head[0] = GW_TBL_MAGIC;
+    }
+}
+
+// The persistent table buffer of a k-distribution: one per (calling thread, device, first index array, shape), zeroed when it is
+// made, validated against the index arrays' CONTENTS by the kernel at every launch. At most 32 are kept (oldest dropped).
+inline int* gas_window_tables(hipStream_t st, const int* key_ptr, const int ngpt, const int nminorlower, const int nminorupper,
+                              const int ncmax, const int nlist)
+{
+    struct Entry { int dev; const int* key; int dims[5]; int* buf; };
+    static thread_local std::vector<Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("no device");
+    const int dims[5] = {ngpt, nminorlower, nminorupper, ncmax, nlist};
+    for (const Entry& e : cache)
+        if (e.dev == dev && e.key == key_ptr && std::equal(dims, dims + 5, e.dims)) return e.buf;
+    (void)st;
+    // (plain hipMalloc / hipMemset, once per k-distribution: the buffer may be used from any stream of this thread afterwards)
+    if (cache.size() >= 32) { (void)hipFree(cache.front().buf); cache.erase(cache.begin()); }
+    const size_t n = size_t(GasWindowTables{ngpt, std::max(nminorlower, nminorupper), ncmax}.ints()) + GW_TBL_HEADER;
+    Entry e{dev, key_ptr, {dims[0], dims[1], dims[2], dims[3], dims[4]}, nullptr};
+    if (hipMalloc(reinterpret_cast<void**>(&e.buf), n*sizeof(int)) != hipSuccess) throw std::runtime_error("table allocation failed");
+    if (hipMemset(e.buf, 0, n*sizeof(int)) != hipSuccess) throw std::runtime_error("memset failed");
+    cache.push_back(e);
+    return e.buf;
 }
 
 template<typename F>
@@ -2277,7 +2325,7 @@ int gas_optics_lw_fractions_impl(
         todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
         if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
         const GasWindowTables T{ngpt, nmax, ncmax};
-        int* tbl = scratch.get<int>(size_t(T.ints()));
+        int* tbl = gas_window_tables(st, gpoint_flavor, ngpt, nminorlower, nminorupper, ncmax, NXW);
         gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
                 ngpt, nminorlower, nminorupper, ncmax, NXW, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                 minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,
@@ -2357,7 +2405,7 @@ int tau_absorption_impl(
             int* todo = scratch.get<int>(size_t(9) + size_t(nblk)*nz) + 8;
             if (hipMemsetAsync(todo - 8, 0, 9*sizeof(int), st) != hipSuccess) throw std::runtime_error("memset failed");
             const GasWindowTables T{ngpt, nmax, ncmax};
-            int* tbl = scratch.get<int>(size_t(T.ints()));
+            int* tbl = gas_window_tables(st, gpoint_flavor, ngpt, nminorlower, nminorupper, ncmax, (MODE == 1) ? NCW : NXW);
             gas_window_tables_kernel<<<1, 256, size_t(T.ints() + ngpt + 4 + 2*((ngpt + 63)/64))*sizeof(int), st>>>(
                     ngpt, nminorlower, nminorupper, ncmax, (MODE == 1) ? NCW : NXW, gpoint_flavor, minor_limits_gpt_lower, minor_limits_gpt_upper,
                     minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower, scale_by_complement_upper,

@@ -345,18 +345,21 @@ lw_noscat_scan_kernel(
 #ifndef RRX_LW_LACC
 #define RRX_LW_LACC 1
 #endif
+#ifndef RRX_LW_LACC32
+#define RRX_LW_LACC32 1    // fp32, two columns per lane: g-point sums in LDS columns too (round 4: the register form spilled 37-41 VGPRs)
+#endif
 #ifndef RRX_LW_EV
 #define RRX_LW_EV 2
 #endif
 // NW = wavefronts per workgroup: 4, or 8 with W = 8 for columns of up to 287 layers (round 3: eight waves x four level-lanes x
 // nine layers; one workgroup per CU then, the same two waves per SIMD).
-// Round 4, fp32: one column per lane, W = 4 and NW = 8 (two column groups per workgroup share each 128-B line of the 64-B rows),
-// compiled for four waves per SIMD -- the geometry of the fp32 SW solver (rrx_solver_sw.hip, CLT note).
+// Round 4, fp32: one column per lane with W = 4 and NW = 8 (two column groups per workgroup share each 128-B line of the 64-B
+// rows) -- the geometry of the fp32 SW solver (rrx_solver_sw.hip, CLT note); here it serves odd column counts only.
 #ifndef RRX_LW_F32_WAVES
 #define RRX_LW_F32_WAVES 2
 #endif
 template<typename F, int V, int K, int W, int CLT, bool LITE, bool PRE, bool GS = false, int EV = RRX_LW_EV, int NW = (W > 4 ? W : 4)>
-__global__ void __launch_bounds__(64*NW, (NW > W) ? (NW >= 12 ? NW/4 : RRX_LW_F32_WAVES) : (NW > 4 ? 1 : 2))
+__global__ void __launch_bounds__(64*NW, (NW > W) ? RRX_LW_F32_WAVES : (NW > 4 ? 1 : 2))
 lw_noscat_bb_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ secants, const F* __restrict__ weights,
@@ -387,7 +390,7 @@ lw_noscat_bb_kernel(
 
     // g-point sums of the lane's K levels: in LDS columns for fp64 (the 4*K registers they would take push the kernel past 256
     // VGPRs into scratch; LDS has room for them at the two workgroups per CU the registers allow), in registers for fp32
-    constexpr bool LACC = RRX_LW_LACC && sizeof(F) == 8 && V == 1;
+    constexpr bool LACC = RRX_LW_LACC && ((sizeof(F) == 8 && V == 1) || (sizeof(F) == 4 && V == 2 && RRX_LW_LACC32));
     __shared__ F lds_acc[LACC ? 2*K*V : 1][64*NW];
     F acc_up[LACC ? 1 : K][V], acc_dn[LACC ? 1 : K][V];
     #pragma unroll
@@ -726,6 +729,21 @@ __global__ void sum_gpt_kernel(const size_t ncl_lev, const int ngpt, const F* __
     out[i] = s;
 }
 
+// the partial sums of the g-point ranges of a fused broadband launch, all flux arrays in one launch (blockIdx.y = array; the
+// partials of array a start at in + a*nsplit*ncl_lev): range order, as sum_gpt_kernel
+template<typename F, int NARR>
+__global__ void sum_ranges_kernel(const size_t ncl_lev, const int nsplit, const F* __restrict__ in, F* const o0, F* const o1, F* const o2)
+{
+    const size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (i >= ncl_lev) return;
+    const int a = blockIdx.y;
+    const F* __restrict__ p = in + size_t(a)*nsplit*ncl_lev;
+    F s = F(0.);
+    for (int ig=0; ig<nsplit; ++ig) s += p[i + size_t(ig)*ncl_lev];
+    F* __restrict__ out = (a == 0) ? o0 : ((a == 1 || NARR < 3) ? o1 : o2);
+    out[i] = s;
+}
+
 
 template<typename F, int V, int K, int W>
 void launch_scan_k(
@@ -821,7 +839,7 @@ bool launch_bb2(
     if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
     const int groups = ceil_div(ncol, (NW/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
-    if (need > ((CLT == 16) ? ((NW > W && W == 6) ? 6 : ((NW > W && W == 8) ? 5 : 9)) : 5)) return false;
+    if (need > ((CLT == 16) ? 9 : 5)) return false;
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
@@ -841,17 +859,11 @@ bool launch_bb2(
             lay_source, lev_source, blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, out_up, out_dn, gper, nlevcol); \
         break; }
     do {
-    if constexpr (CLT == 16 && W == 6 && NW > W) { RRX_LW_B2(6) }
-    else if constexpr (CLT == 16 && W == 8 && NW > W) { RRX_LW_B2(5) }
-    else if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
+    if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
     else                     { RRX_LW_B2(2) RRX_LW_B2(3) RRX_LW_B2(5) }
     } while (false);
-    if (nsplit > 1)
-    {
-        const int nb = ceil_div(nlevcol, 256);
-        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, out_up, flux_up);
-        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, out_dn, flux_dn);
-    }
+    if (nsplit > 1)      // (out_up, out_dn lie behind each other in the scratch block)
+        sum_ranges_kernel<F,2><<<dim3(ceil_div(nlevcol, 256), 2), 256, 0, st>>>(nlevcol, nsplit, out_up, flux_up, flux_dn, (F*)nullptr);
     return true;
 #undef RRX_LW_B2
 }
@@ -881,15 +893,11 @@ bool lw_fused_broadband(
     else
     {
         // one column per lane, two column groups per workgroup, four waves per SIMD (variant 15 = the forms of rounds 1-3)
-        if (tuning().lw_variant == 16 &&      // A/B: six waves x six layers, one 768-thread workgroup per CU, three waves per SIMD
-            launch_bb2<F,1,6,16,LITE,12>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
-                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
-            return true;
-        if (tuning().lw_variant == 17 &&      // A/B: eight waves x five layers, one 1024-thread workgroup per CU, four waves per SIMD
-            launch_bb2<F,1,8,16,LITE,16>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
-                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
-            return true;
-        if (tuning().lw_variant != 15 &&
+        // Round 4 measured the one-column-per-lane geometries of the SW solver here too (K = 9 / W = 4 at two waves per SIMD, K = 6 /
+        // W = 6 at three, K = 5 / W = 8 at four: 1.82 / 1.88 / 1.95 ms at C4 against 1.31 for two columns per lane with the sums in
+        // LDS, profiles/r04_fp32_geometry_ab.txt): the LW chain per g-point is short, so halving the wavefronts per column wins.
+        // The one-column form stays for odd column counts (variant 15 forces it for tests).
+        if (tuning().lw_variant == 15 &&
             launch_bb2<F,1,4,16,LITE,8>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;
@@ -910,7 +918,9 @@ bool lw_fused_broadband(
             launch_bb2<F,2,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;
-        return false;
+        // odd column counts: one column per lane
+        return launch_bb2<F,1,4,16,LITE,8>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                           blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
     }
 }
 
@@ -940,7 +950,7 @@ int lw_solver_noscat_impl(
     // to fill the chip one workgroup sums all g-points in order (sum_broadband's order); with fewer the g-point range is split
     // over grid.y and the partial sums are added in range order (rrx::broadband_gsplit).
     constexpr int VBB = (sizeof(F) == 8) ? 1 : 2;
-    const bool second_gen = (g_lw_variant == 0 || (g_lw_variant >= 13 && g_lw_variant <= 17));        // splits its g-point loop when columns are few
+    const bool second_gen = (g_lw_variant == 0 || (g_lw_variant >= 13 && g_lw_variant <= 15));        // splits its g-point loop when columns are few
     if (do_broadband && !jac && nmus == 1 && g_lw_variant != 1 && g_lw_variant != 7 && (ncol % VBB == 0 || (second_gen && sizeof(F) == 4))
         && (second_gen || ceil_div(ncol, CL*VBB) >= g_bb_min_groups))
     {
@@ -1074,7 +1084,7 @@ int lw_solver_noscat_fractions_impl(
         if (ncol <= 0 || nlay <= 0 || ngpt <= 0) throw std::runtime_error("empty problem");
         if (flux_up_loc == nullptr || flux_dn_loc == nullptr) throw std::runtime_error("broadband outputs missing");
         const int var = tuning().lw_variant;
-        if ((var == 0 || (var >= 13 && var <= 17)) &&
+        if ((var == 0 || (var >= 13 && var <= 15)) &&
             lw_fused_broadband<F,true>(st, ncol, nlay, ngpt, top_at_1, secants, weights, tau, pfrac, (const F*)nullptr,
                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up_loc, flux_dn_loc))
             return check_launch("rrx_lw_solver_noscat_fractions");

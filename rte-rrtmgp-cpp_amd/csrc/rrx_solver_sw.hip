@@ -117,11 +117,15 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // the two-wave case of the same composition, kept as it was).
 // CLT = column lanes per wavefront (level lanes = 64 / CLT). 8 x 8 is the fp64 geometry (64-B rows per wave, two column groups per
 // workgroup share each 128-B line). Round 4, fp32: 16 x 4 lanes with ONE column per lane, four waves per column group and two groups
-// per workgroup -- the same nine cells per lane and the same 64-B rows as fp64, half the registers: four waves per SIMD, which is
-// where the fp32 pipe issues an instruction every 2.0 cycles (3.5 at two waves; packed v_pk_fma_f32 costs 3.8 whatever the
-// occupancy, profiles/r04_fp32_issue_costs.txt, so two columns per lane on packed math buy nothing).
+// per workgroup -- the same nine cells per lane and the same 64-B rows as fp64, no scratch (the two-columns-per-lane form of rounds
+// 1-3 spilled 25-34 VGPRs): 3.70 -> 3.33 ms at C4 clear sky, 8.06 -> 7.5 ms all-sky at 32 768 columns. What was measured on the
+// way (profiles/r04_issue_costs_fp32.txt, r04_fp32_geometry_ab.txt): packed v_pk_fma_f32 issues every 3.8 cycles against 2.0 for
+// v_fma_f32 at four waves per SIMD (5.7 against 3.5 at two), so two columns per lane on packed math buy at most a fifth of the
+// packable instructions; compiled for four waves per SIMD (128 VGPRs) this geometry spills 36-65 registers and is slower (4.44 /
+// 12.8 ms); K = 6 with six waves per column group (three waves per SIMD, no spills) 3.43 / 7.95 ms and K = 5 with eight (four
+// per SIMD) 3.61 / 8.6 ms: the wider exchanges cost what the occupancy brings.
 template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false, int NW = (W > 2 ? 2*W : 4), int CLT = 8>
-__global__ void __launch_bounds__(64*NW, (CLT == 16) ? (NW >= 12 ? NW/4 : (K <= 9 ? RRX_SW_F32_WAVES : 2)) : ((NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)))
+__global__ void __launch_bounds__(64*NW, (CLT == 16) ? RRX_SW_F32_WAVES : ((NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)))
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
@@ -700,6 +704,21 @@ __global__ void sum_gpt_kernel(const size_t ncl_lev, const int ngpt, const F* __
     out[i] = s;
 }
 
+// the partial sums of the g-point ranges of a fused broadband launch, all flux arrays in one launch (blockIdx.y = array; the
+// partials of array a start at in + a*nsplit*ncl_lev): range order, as sum_gpt_kernel
+template<typename F, int NARR>
+__global__ void sum_ranges_kernel(const size_t ncl_lev, const int nsplit, const F* __restrict__ in, F* const o0, F* const o1, F* const o2)
+{
+    const size_t i = size_t(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (i >= ncl_lev) return;
+    const int a = blockIdx.y;
+    const F* __restrict__ p = in + size_t(a)*nsplit*ncl_lev;
+    F s = F(0.);
+    for (int ig=0; ig<nsplit; ++ig) s += p[i + size_t(ig)*ncl_lev];
+    F* __restrict__ out = (a == 0) ? o0 : ((a == 1 || NARR < 3) ? o1 : o2);
+    out[i] = s;
+}
+
 template<typename F>
 __global__ void apply_BC_kernel(const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ inc_flux, const F* __restrict__ factor, F* __restrict__ flux_dn)
@@ -743,7 +762,7 @@ bool launch_scan_bb(hipStream_t st,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
     constexpr int NW = (W > 2) ? 2*W : 4;                 // wavefronts per workgroup: two column groups
-    constexpr int KMAX = (CLT == 16) ? (W == 6 ? 6 : (W == 8 ? 5 : 12)) : (W > 2 ? 9 : 12);       // (8 x 8 lanes, W = 4: nine layers per lane fill the LDS of a CU)
+    constexpr int KMAX = (CLT == 16) ? 12 : (W > 2 ? 9 : 12);       // (8 x 8 lanes, W = 4: nine layers per lane fill the LDS of a CU)
     const int groups = ceil_div(ncol, 2*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
     if (need > KMAX) return false;
@@ -775,20 +794,13 @@ bool launch_scan_bb(hipStream_t st,
 #define RRX_SW_K(KK) if (need <= KK) { launch(std::integral_constant<int,KK>{}); break; }
     do
     {
-        if constexpr (CLT == 16 && W == 6) { RRX_SW_K(6) }
-        else if constexpr (CLT == 16 && W == 8) { RRX_SW_K(5) }
-        else if constexpr (CLT == 16) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
+        if constexpr (CLT == 16) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
         else if constexpr (W == 2) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
         else { RRX_SW_K(9) }
     } while (false);
 #undef RRX_SW_K
-    if (nsplit > 1)
-    {
-        const int nb = ceil_div(nlevcol, 256);
-        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, up, flux_up);
-        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, dn, flux_dn);
-        sum_gpt_kernel<F><<<nb, 256, 0, st>>>(nlevcol, nsplit, dr, flux_dir);
-    }
+    if (nsplit > 1)      // (up, dn, dr lie behind each other in the scratch block)
+        sum_ranges_kernel<F,3><<<dim3(ceil_div(nlevcol, 256), 3), 256, 0, st>>>(nlevcol, nsplit, up, flux_up, flux_dn, flux_dir);
     return true;
 }
 
@@ -821,14 +833,6 @@ int sw_solver_2stream_impl(
         // per-lane form of rounds 1-3 for A/B runs
         if constexpr (sizeof(F) == 4)
         {
-            if (g_sw_variant == 10 &&       // A/B: six waves x six layers, one 768-thread workgroup per CU, three waves per SIMD
-                launch_scan_bb<F,1,6,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                         inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
-                return 0;
-            if (g_sw_variant == 11 &&       // A/B: eight waves x five layers, one 1024-thread workgroup per CU, four waves per SIMD
-                launch_scan_bb<F,1,8,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
-                                         inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
-                return 0;
             if (g_sw_variant != 9 &&
                 launch_scan_bb<F,1,4,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                          inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))

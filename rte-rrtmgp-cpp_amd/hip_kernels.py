@@ -411,6 +411,12 @@ class HipKernels:
         self._c("spread_col", ncol, solar_source.shape[0], out, solar_source)
         return out
 
+    def toa_source(self, ncol, solar_source, tsi_scaling):
+        """spread_col + scaling_to_subset in one launch: toa_src(igpt, icol) = solar_source(igpt) * tsi_scaling(icol)."""
+        out = self.empty((solar_source.shape[0], ncol))
+        self._c("toa_source", ncol, solar_source.shape[0], out, solar_source, tsi_scaling)
+        return out
+
     def scaling_to_subset(self, toa_src, tsi_scaling):
         ngpt, ncol = toa_src.shape
         self._c("scaling_to_subset", ncol, ngpt, toa_src, tsi_scaling)

@@ -366,8 +366,7 @@ class ResidentSolver:
                     be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf, by_band=cld if fuse else None)
                 else:
                     be.gas_optics_sw_fused(kd, it, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf)
-                toa = be.spread_col(ncol, kd.solar_source)
-                be.scaling_to_subset(toa, atm.tsi_scaling)
+                toa = be.toa_source(ncol, kd.solar_source, atm.tsi_scaling)     # spread_col + scaling_to_subset, one launch
                 if cld is not None and not fuse:
                     be.inc_2stream_by_2stream_bybnd(buf["tau"], buf["ssa"], gbuf, *cld, kd.band_lims_gpt)
                 mark("sw_gas_optics", True)

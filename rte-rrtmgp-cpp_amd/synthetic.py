@@ -272,17 +272,17 @@ def make_atmosphere(ncol, nlay=140, nbnd_lw=16, nbnd_sw=16, seed=1234, top_at_1=
     col_range = (start, stop): only those columns of the ncol-column atmosphere are built (a rank's share of a sharded job:
     column c is the same column whatever the range), without ever holding the whole domain."""
     if col_range is not None:
-        if clouds or aerosols:
-            raise ValueError("col_range is for the clear-sky benchmark atmosphere")
+        if aerosols:
+            raise ValueError("col_range is for the benchmark atmospheres (clear sky, clouds)")
         s_, e_ = col_range
         rng = np.random.default_rng(seed)
         dT_all = rng.uniform(-1.0, 1.0, size=ncol); dq_all = rng.uniform(0.95, 1.05, size=ncol)
-        return _make_atmosphere(e_ - s_, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, False, z_top, False,
-                                _perturbation=(dT_all[s_:e_], dq_all[s_:e_]))
+        return _make_atmosphere(e_ - s_, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, False,
+                                _perturbation=(dT_all[s_:e_], dq_all[s_:e_]), _col0=s_)
     return _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, aerosols)
 
 
-def _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, aerosols, _perturbation=None):
+def _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top, aerosols, _perturbation=None, _col0=0):
     rng = np.random.default_rng(seed)
     dz = z_top / nlay
     z = dz/2 + dz*np.arange(nlay)
@@ -318,7 +318,7 @@ def _make_atmosphere(ncol, nlay, nbnd_lw, nbnd_sw, seed, top_at_1, clouds, z_top
         mu0=np.full(ncol, np.cos(np.deg2rad(42.05))), tsi_scaling=np.full(ncol, 551.58/1360.85),
     )
     if clouds:
-        flag = (np.arange(1, ncol+1) % 3 > 0)
+        flag = ((np.arange(1, ncol+1) + _col0) % 3 > 0)          # (global column index: a rank's share is the same columns)
         mask = (atm["p_lay"] > 1.e4) & (atm["p_lay"] < 9.e4) & flag[None, :]
         atm["lwp"] = np.where(mask & (atm["t_lay"] > 263.), 10., 0.)
         atm["iwp"] = np.where(mask & (atm["t_lay"] < 273.), 10., 0.)

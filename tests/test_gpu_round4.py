@@ -1,0 +1,155 @@
+"""GPU tests of what round 4 changed (run on the MI355X box: pytest -m gpu); everything goes through the C ABI.
+
+  * fp32 fused broadband solvers in the one-column-per-lane geometry (odd column counts, with and without g, all tilings);
+  * the persistent index tables of the windowed gas optics are validated against the k-distribution's CONTENTS;
+  * the workspace of the any-nlay solver forms belongs to its stream and is handed back;
+  * the small kernels that were rewritten (toa source, range sums, gather grid).
+"""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+import cases
+from rte_rrtmgp_cpp_amd import synthetic, pipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_columns(rng, ngpt, nlay, ncol):
+    tau = 10.0**rng.uniform(-5, 1.5, (ngpt, nlay, ncol)); ssa = rng.uniform(0, 1, tau.shape); g = rng.uniform(0, .9, tau.shape)
+    lay = rng.uniform(5, 40, tau.shape); lev = rng.uniform(5, 40, (ngpt, nlay+1, ncol))
+    e2 = rng.uniform(.5, 1, (ngpt, ncol)); mu0 = rng.uniform(.1, 1, ncol)
+    return tau, ssa, g, lay, lev, e2, mu0
+
+
+@pytest.mark.parametrize("with_g", [True, False], ids=["g", "no-g"])
+@pytest.mark.parametrize("ncol,nlay,top_at_1", [(33, 140, False), (17, 60, True), (129, 20, False), (40, 143, True), (31, 190, False)])
+def test_fp32_broadband_solvers_one_column_per_lane(ncol, nlay, top_at_1, with_g, hip_f32, oracle_f32):
+    """fp32 do_broadband: the 16 x 4-lane geometry (SW default; LW for odd column counts and under variant 15) against the fp32
+    oracle, on odd and even column counts, every K of the tiling (20 ... 190 layers), with g (all-sky form, pipelined loads of tau,
+    ssa AND g) and without (clear-sky form). Bounds as for the other fp32 solver tests (random optical properties sit on the
+    two-stream clamps: 1e-3 there)."""
+    rng = np.random.default_rng(100*nlay + ncol)
+    ngpt = 6
+    tau, ssa, g, lay, lev, e2, mu0 = _random_columns(rng, ngpt, nlay, ncol)
+    out = []
+    for be, lwv in ((hip_f32, 15), (hip_f32, 0), (oracle_f32, 0)):
+        up = be.asarray
+        if be is hip_f32:
+            be.set_variant(lw=lwv)
+        try:
+            sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+            l = be.lw_solver_noscat(top_at_1, sec, w, up(tau), up(lay), up(lev), up(e2), up(e2*20), inc_flux=up(e2*3), do_broadband=True)
+            gg = up(g) if with_g else (None if be is hip_f32 else be.zeros(tau.shape))
+            s = be.sw_solver_2stream(top_at_1, up(tau), up(ssa), gg, up(mu0), up(e2*.5), up(e2*.4), up(e2*3), inc_flux_dif=up(e2*.2),
+                                     do_broadband=True)
+        finally:
+            if be is hip_f32:
+                be.set_variant(lw=0)
+        out.append([be.to_numpy(x) for x in (l["flux_up"], l["flux_dn"], s["flux_up"], s["flux_dn"], s["flux_dir"])])
+    for name, a15, a0, o in zip(("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dir"), *out):
+        assert a0.shape == o.shape == (nlay+1, ncol)
+        tol = 2e-5 if name.startswith("lw") else 1e-3
+        assert cases.rel_err(a0, o, floor=1e-2) <= tol, name
+        assert cases.rel_err(a15, o, floor=1e-2) <= tol, name + " (one column per lane)"
+
+
+def test_fp32_sw_geometries_agree(hip_f32):
+    """The two fp32 SW tilings (one column per lane, default; two columns per lane, variant 9) on the same inputs."""
+    rng = np.random.default_rng(5)
+    ngpt, nlay, ncol = 5, 140, 64
+    tau, ssa, g, _, _, e2, mu0 = _random_columns(rng, ngpt, nlay, ncol)
+    be = hip_f32; up = be.asarray
+    res = []
+    for v in (0, 9):
+        be.set_variant(sw=v)
+        try:
+            s = be.sw_solver_2stream(False, up(tau), up(ssa), up(g), up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=True)
+        finally:
+            be.set_variant(sw=0)
+        res.append([be.to_numpy(s[k]) for k in ("flux_up", "flux_dn", "flux_dir")])
+    for a, b in zip(*res):
+        assert cases.rel_err(a, b, floor=1e-2) <= 1e-3
+
+
+def test_window_tables_follow_the_contents_not_the_pointers(hip_f64, oracle_f64):
+    """The windowed gas optics keeps its index tables per k-distribution between launches and validates them against the index
+    arrays' contents at every launch. Overwriting a k-distribution IN PLACE (same device addresses, other flavors / contributor
+    intervals) must give the new k-distribution's optical depths."""
+    be, orc = hip_f64, oracle_f64
+    atm0 = synthetic.make_atmosphere(256, 24, nbnd_lw=4, nbnd_sw=4)
+    kds = [synthetic.make_kdist("lw", ngpt=64, nbnd=4, npres=14, nflav=4, nminor_lower=6, nminor_upper=4, seed=s) for s in (3, 4)]
+    dev = be.upload_kdist(kds[0])
+    atm = pipeline.upload_atmosphere(be, atm0)
+    for i, kd0 in enumerate(kds):
+        if i > 0:                                   # second k-distribution written over the first one's device arrays
+            other = be.upload_kdist(kd0)
+            for name, t in vars(dev).items():
+                src = getattr(other, name)
+                if torch.is_tensor(t):
+                    assert t.shape == src.shape, name
+                    t.copy_(src)
+                elif not isinstance(t, (list, tuple, dict)):
+                    setattr(dev, name, src)
+            torch.cuda.synchronize()
+        got = pipeline.solve_lw(be, dev, atm, do_broadband=True)
+        ref = pipeline.solve_lw(orc, orc.upload_kdist(kd0), pipeline.upload_atmosphere(orc, atm0), do_broadband=True)
+        for k in ("flux_up", "flux_dn"):
+            assert cases.rel_err(be.to_numpy(got[k]), orc.to_numpy(ref[k])) <= 1e-9, (i, k)
+
+
+def test_workspace_belongs_to_its_stream(hip_f64):
+    """the grow-only block of the any-nlay solver forms is owned by the stream: repeated general-path calls reuse ONE
+    block (device memory does not grow), rrx_release_workspace / rrx_stream_destroy hand it back, and the fractions entry and the
+    general entry it calls share one lease (results equal those of separately provided arrays)."""
+    be = hip_f64
+    lib = be.lib.cdll
+    lib.rrx_workspace_bytes.restype = ctypes.c_ulonglong
+    rng = np.random.default_rng(9)
+    ngpt, nlay, ncol = 4, 300, 48                      # 300 layers: beyond every fused tiling -> workspace forms
+    tau, ssa, g, lay, lev, e2, mu0 = _random_columns(rng, ngpt, nlay, ncol)
+    up = be.asarray
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def solve():
+        sec = be.lw_secants_array(ncol, ngpt, 1, 4, up(pipeline.GAUSS_DS)); w = up(np.array([1.0]))
+        l = be.lw_solver_noscat(False, sec, w, up(tau), up(lay), up(lev), up(e2), up(e2*20), do_broadband=True)
+        s = be.sw_solver_2stream(False, up(tau), up(ssa), up(g), up(mu0), up(e2*.5), up(e2*.4), up(e2*3), do_broadband=True)
+        return be.to_numpy(l["flux_up"]), be.to_numpy(s["flux_up"])
+
+    first = solve()
+    torch.cuda.synchronize()
+    size1 = lib.rrx_workspace_bytes(stream)
+    assert size1 > 0
+    free1 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        again = solve()
+    torch.cuda.synchronize()
+    assert lib.rrx_workspace_bytes(stream) == size1
+    assert torch.cuda.mem_get_info()[0] >= free1 - (8 << 20), "device memory grew across general-path calls"
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    assert lib.rrx_release_workspace(stream) == 0
+    assert lib.rrx_workspace_bytes(stream) == 0
+    # a stream of our own: the block goes with the stream
+    s2 = ctypes.c_void_p()
+    assert lib.rrx_stream_create(ctypes.byref(s2)) == 0
+    with torch.cuda.stream(torch.cuda.ExternalStream(s2.value)):
+        solve()
+        torch.cuda.synchronize()
+        assert lib.rrx_workspace_bytes(s2) > 0
+    assert lib.rrx_stream_destroy(s2) == 0
+    assert lib.rrx_workspace_bytes(s2) == 0
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_toa_source_equals_spread_then_scale(dt, hip_f64, hip_f32):
+    be = hip_f64 if dt == "f64" else hip_f32
+    rng = np.random.default_rng(2)
+    for ncol, ngpt in ((1, 1), (257, 7), (2048, 224)):
+        src = be.asarray(rng.uniform(0.1, 5, ngpt)); tsi = be.asarray(rng.uniform(0.3, 1.2, ncol))
+        a = be.spread_col(ncol, src); be.scaling_to_subset(a, tsi)
+        b = be.toa_source(ncol, src, tsi)
+        assert np.array_equal(be.to_numpy(a), be.to_numpy(b))
+        assert np.array_equal(be.to_numpy(a), (be.to_numpy(src)[:, None] * be.to_numpy(tsi)[None, :]).astype(be.np_dtype))
