@@ -225,8 +225,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncol", type=int, default=128*128, help="columns per GPU (weak scaling) or in total (strong); C4 = 128 x 128")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --ncol columns on every GPU; strong: --ncol columns sharded over the GPUs (BASELINE C4 on 8 GPUs = 2048 each)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default for --gpus N > 1): --ncol columns sharded over the GPUs (BASELINE C4: 16 384 columns on 8 GPUs = 2 048 each); "
+                         "weak: --ncol columns on every GPU. With N > 1 the other one is measured too and reported as `other_scaling`")
+    ap.add_argument("--one-scaling", action="store_true", help="N > 1: skip the second measurement (the other scaling)")
     ap.add_argument("--dry-run", action="store_true", help="print the launch command of a multi-GPU run and exit")
     ap.add_argument("--nlay", type=int, default=140)
     ap.add_argument("--ngpt", type=int, default=256)
@@ -253,12 +255,17 @@ def main():
                     help="BASELINE's all-sky flow (C5): cloud optics added by band after the gas optics, delta-scaled in SW; not the headline workload")
     args = ap.parse_args()
     args.broadband = (args.flux_mode == "broadband" or args.broadband) and not args.per_gpoint
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     # `python bench.py --gpus N` on its own: become the launcher of N ranks. This happens before torch is imported, so this
     # process never initialises the GPU; the ranks are children (never an exec of a process that holds a GPU context).
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         cmd = launch_command(sys.argv[1:], args.gpus)
         if args.dry_run:
+            ntot = global_columns(args, args.gpus)       # (sharding.column_range's split, without importing torch in the launcher)
+            print(f"# scaling {args.scaling}: {ntot} columns over {args.gpus} ranks:",
+                  [ntot // args.gpus + (1 if r < ntot % args.gpus else 0) for r in range(args.gpus)])
             print(" ".join(cmd)); return 0
         import subprocess
         env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -291,62 +298,79 @@ def main():
     kd_lw0 = synthetic.make_kdist("lw", ngpt=args.ngpt, nbnd=nbnd)
     kd_sw0 = synthetic.make_kdist("sw", ngpt=args.ngpt, nbnd=nbnd)
     kd_lw, kd_sw = be.upload_kdist(kd_lw0), be.upload_kdist(kd_sw0)
-    # rank r owns the contiguous column range sharding.column_range(r, world, ntot) of ONE global atmosphere
-    ntot = global_columns(args, world)
-    (col_s, col_e), atm0 = local_atmosphere(args, nbnd, rank, world)
     cloud_luts = None
     if args.allsky:
         cast = lambda lut: be.upload_lut({k: (v.astype(np_dtype) if isinstance(v, np.ndarray) else v) for k, v in lut.items()})
         cloud_luts = (cast(synthetic.make_cloud_lut(nbnd, "lw")), cast(synthetic.make_cloud_lut(nbnd, "sw")))
-    ncol_local = col_e - col_s
-    atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
-    solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts,
-                                     sort_columns=args.sort_columns)
-    do_gather = world > 1 and not args.no_gather
-    gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
 
-    def one_step():
-        F = solver.step()
+    def measure(scaling, primary):
+        """One job: rank r owns the contiguous column range sharding.column_range(r, world, ntot) of ONE global atmosphere (only its
+        own columns are ever built, clouds included). W warm-up steps, then exactly K timed steps between barrier + synchronize
+        pairs; the time is the maximum over the ranks."""
+        a = argparse.Namespace(**vars(args)); a.scaling = scaling
+        ntot = global_columns(a, world)
+        (col_s, col_e), atm0 = local_atmosphere(a, nbnd, rank, world)
+        atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
+        solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts,
+                                         sort_columns=args.sort_columns)
+        do_gather = world > 1 and not args.no_gather
+        gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
+
+        def one_step():
+            F = solver.step()
+            if gatherer is not None:
+                gatherer.gather(F)          # the one collective of the path (tests/test_dist_gloo.py runs this code on gloo)
+
+        for _ in range(args.warmup):
+            one_step()
         if gatherer is not None:
-            gatherer.gather(F)          # the one collective of the path (tests/test_dist_gloo.py runs this code on gloo)
+            gatherer.finish()
+        # one untimed step with the windowed gas optics' hand-back census switched on (it synchronises the stream per launch)
+        handed = None
+        if primary and rank == 0 and be.lib.has("rrx_gas_window_stats"):
+            import ctypes
+            os.environ["RRX_GW_STATS"] = "1"
+            be.lib.cdll.rrx_gas_window_stats(None, None, 1)
+            devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(2); os.dup2(devnull, 2)      # (the census also prints to stderr)
+            try:
+                solver.step(); torch.cuda.synchronize()
+            finally:
+                os.dup2(saved, 2); os.close(saved); os.close(devnull); del os.environ["RRX_GW_STATS"]
+            c1, c2 = ctypes.c_longlong(0), ctypes.c_longlong(0)
+            be.lib.cdll.rrx_gas_window_stats(ctypes.byref(c1), ctypes.byref(c2), 1)
+            if c2.value > 0:
+                handed = {"handed_back": int(c1.value), "workgroups": int(c2.value), "frac": round(c1.value / c2.value, 4)}
+        if primary:
+            solver.enable_stage_events(args.steps)
 
-    for _ in range(args.warmup):
-        one_step()
-    if gatherer is not None:
-        gatherer.finish()
-    # one untimed step with the windowed gas optics' hand-back census switched on (it synchronises the stream per launch)
-    handed = None
-    if rank == 0 and be.lib.has("rrx_gas_window_stats"):
-        import ctypes
-        os.environ["RRX_GW_STATS"] = "1"
-        be.lib.cdll.rrx_gas_window_stats(None, None, 1)
-        devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(2); os.dup2(devnull, 2)      # (the census also prints to stderr)
-        try:
-            solver.step(); torch.cuda.synchronize()
-        finally:
-            os.dup2(saved, 2); os.close(saved); os.close(devnull); del os.environ["RRX_GW_STATS"]
-        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
-        be.lib.cdll.rrx_gas_window_stats(ctypes.byref(a), ctypes.byref(b), 1)
-        if b.value > 0:
-            handed = {"handed_back": int(a.value), "workgroups": int(b.value), "frac": round(a.value / b.value, 4)}
-    solver.enable_stage_events(args.steps)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        if gatherer is not None:
+            gatherer.finish()               # the last exchange is inside the timed region
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dict(dt=dt, ntot=ntot, ncol_local=col_e - col_s, solver=solver, handed=handed)
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    if gatherer is not None:
-        gatherer.finish()               # the last exchange is inside the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    m = measure(args.scaling, True)
+    dt, ntot, ncol_local, solver, handed = m["dt"], m["ntot"], m["ncol_local"], m["solver"], m["handed"]
+    # N > 1: the other way of growing the job, measured in the same run (VERDICT r03: BASELINE C4 shards 16 384 columns over the
+    # GPUs = strong, which is `value`; the weak line -- 16 384 columns on every GPU -- rides along)
+    other = None
+    if world > 1 and not args.one_scaling:
+        o = measure("weak" if args.scaling == "strong" else "strong", False)
+        other = {"scaling": "weak" if args.scaling == "strong" else "strong", "value": round(o["ntot"] * args.steps / o["dt"], 1),
+                 "ms_per_step": round(o["dt"] / args.steps * 1e3, 3), "columns_per_gpu": o["ncol_local"], "columns_total": o["ntot"]}
+        del o
 
     if rank == 0:
         S = np_dtype().itemsize
@@ -390,6 +414,8 @@ def main():
                 out["roofline_valu"]["stale"] = bool(stale)
         if handed is not None:
             out["gas_window"] = handed
+        if other is not None:
+            out["other_scaling"] = other
         if world > 1:       # what a SCALE record can be checked against
             out["ranks_seen"] = dist.get_world_size()
             out["columns_per_rank"] = [int(e - s) for s, e in (sharding.column_range(r, world, ntot) for r in range(world))]

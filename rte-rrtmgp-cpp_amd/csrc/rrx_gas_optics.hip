@@ -1560,7 +1560,7 @@ inline int* gas_window_tables(hipStream_t st, const int* key_ptr, const int ngpt
 template<typename F>
 size_t gas_window_lds_bytes(const int ngpt, const int nmax, const int ncmax, const int mode, const bool pf)
 {
-    const size_t ints = size_t(GasWindowTables{ngpt, nmax, ncmax}.ints()) + 16;
+    const size_t ints = size_t(GasWindowTables{ngpt, nmax, ncmax}.ints()) + 16 + 8*size_t(ncmax);      // tables, reductions, per-chunk bands and key species
     const size_t pairs = size_t(GCH)*WBOX*(pf ? 2 : 1) + size_t(NCW)*GCH*MBOX + (mode == 1 ? size_t(GCH)*MBOX : 0);
     return ((ints*sizeof(int) + 15) & ~size_t(15)) + pairs*2*sizeof(F);
 }
@@ -1605,7 +1605,12 @@ gas_window_kernel(
     int* mmeta = lds_int + T.off_mmeta();                   // [2][nmax][MM]
     int* cuni = lds_int + T.off_cuni();                     // [2][ncmax]: chunk usable by the windowed path (per regime)
     int* red = lds_int + T.ints();                          // [16] workgroup reductions (behind the copied tables)
-    const size_t int_bytes = ((size_t(T.ints()) + 16)*sizeof(int) + 15) & ~size_t(15);
+    // per-chunk band numbers of the fractions form and of the by-band (all-sky) properties, looked up ONCE at set-up: read from global
+    // memory at the top of a chunk (round 3) each look-up was a dependent load that queues behind the stores of the chunk before --
+    // 3-5 k clocks, and the all-sky band search made several of them per chunk (phase clocks: chunk prologue +45 ... +85 k per workgroup)
+    int* cband = red + 16;                                  // [ncmax][8]: PF first band, PF last band, CLD band, CLD chunk in one band,
+                                                            //             key species (gas1, gas2) of the chunk's flavor in the lower / upper atmosphere
+    const size_t int_bytes = ((size_t(T.ints()) + 16 + 8*size_t(ncmax))*sizeof(int) + 15) & ~size_t(15);
     Vec2* Wmaj = reinterpret_cast<Vec2*>(reinterpret_cast<char*>(lds_int) + int_bytes);     // [GCH][WBOX]
     Vec2* Wpf  = Wmaj + GCH*WBOX;                                                           // [GCH][WBOX] (PF)
     Vec2* Wmin = Wpf + (PF ? GCH*WBOX : 0);                                                 // [NCW][GCH][MBOX]
@@ -1641,6 +1646,23 @@ gas_window_kernel(
     __syncthreads();                                  // the tables and the reduction slots are in place
     atomicMin(&red[0], jt); atomicMax(&red[1], jt); atomicMin(&red[2], jp); atomicMax(&red[3], jp);
     atomicMin(&red[4], itr); atomicMax(&red[5], itr);
+    if (tid < cinfo[0])
+    {
+        const int c0_ = cstart[tid], ge_ = cstart[tid+1];
+        if constexpr (PF) { cband[8*tid] = pa.gpoint_bands[c0_] - 1; cband[8*tid+1] = pa.gpoint_bands[ge_-1] - 1; }
+        if constexpr (CLD)
+        {
+            int b0 = 0;
+            while (c0_ + 1 > ia.cld_lims[2*b0+1]) ++b0;
+            cband[8*tid+2] = b0; cband[8*tid+3] = (ge_ <= ia.cld_lims[2*b0+1]) ? 1 : 0;
+        }
+        #pragma unroll
+        for (int r=0; r<2; ++r)
+        {
+            const int fl_ = gflav[r*ngpt + c0_];
+            cband[8*tid+4+2*r] = ia.flavor[2*fl_]; cband[8*tid+5+2*r] = ia.flavor[2*fl_+1];
+        }
+    }
     __syncthreads();
     const int jt_lo = red[0], jp_lo = red[2];
     // grid.z parts share out the chunks of a workgroup when the (column, layer) grid alone leaves CUs idle (few columns per GPU).
@@ -1753,7 +1775,7 @@ gas_window_kernel(
         if (fl != cur_flav)                                            // workgroup-uniform
         {
             cur_flav = fl;
-            const int gas1 = ia.flavor[2*fl], gas2 = ia.flavor[2*fl+1];
+            const int gas1 = rfl(cband[8*c+4+2*rfl(itr)]), gas2 = rfl(cband[8*c+5+2*rfl(itr)]);     // (= ia.flavor[2*fl], [2*fl+1], looked up at set-up)
             const F cg1 = col_gas[idx + size_t(gas1)*ncl], cg2 = col_gas[idx + size_t(gas2)*ncl];
             #pragma unroll
             for (int itemp=0; itemp<2; ++itemp)
@@ -1784,6 +1806,35 @@ gas_window_kernel(
         const int n_all = rfl(lists[(itr_s*ncmax + c)*LIT]);             // (at most NXW here: the chunk is usable)
         const int n = min(n_all, NCW);                                   // contributors of the g-point loop; the others follow behind it
         const int* items = lists + (itr_s*ncmax + c)*LIT + 1;            // contributor indices of the chunk
+
+        // all-sky: the cell's by-band values, read once per chunk where the chunk lies in one band (the rule), requested HERE -- ahead
+        // of the barrier and the staging, whose wait they share
+        [[maybe_unused]] auto cld_arrived = [&]()
+        {
+            if constexpr (CLD)
+            {
+                if constexpr (MODE != 2) asm volatile("" : "+v"(c_tau), "+v"(c_ssa), "+v"(c_g));
+                else asm volatile("" : "+v"(c_tau));
+            }
+        };
+        [[maybe_unused]] auto cld_load = [&](const int ib)
+        {
+            if constexpr (CLD)
+            {
+                cb_have = ib;
+                const size_t b = idx + size_t(ib)*ncl;
+                c_tau = ia.cld_tau[b];
+                if constexpr (MODE != 2) { c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b]; }
+            }
+        };
+        [[maybe_unused]] bool cld_one_band = false;
+        if constexpr (CLD)
+        {
+            const int b0 = rfl(cband[8*c+2]);
+            cb = b0;
+            cld_one_band = rfl(cband[8*c+3]) != 0;
+            if (cld_one_band && b0 != cb_have) cld_load(b0);
+        }
 
         RRX_GW_T(1)
         __syncthreads();                        // the previous chunk's readers are done with the windows
@@ -2016,31 +2067,11 @@ gas_window_kernel(
                 }
             }
         };
-        // all-sky: the cell's by-band values, read once per chunk where the chunk lies in one band (the rule) -- like the band look-up
-        // of the fractions form, a read inside the loop is waited for behind the stores in flight
-        [[maybe_unused]] auto cld_load = [&](const int ib)
-        {
-            if constexpr (CLD)
-            {
-                cb_have = ib;
-                const size_t b = idx + size_t(ib)*ncl;
-                c_tau = ia.cld_tau[b];
-                if constexpr (MODE != 2) { c_ssa = ia.cld_ssa[b]; c_g = ia.cld_g[b]; }
-            }
-        };
-        [[maybe_unused]] bool cld_one_band = false;
-        if constexpr (CLD)
-        {
-            int b0 = 0;
-            while (c0 + 1 > rfl(ia.cld_lims[2*b0+1])) ++b0;
-            cb = b0;
-            cld_one_band = gend <= rfl(ia.cld_lims[2*b0+1]);
-            if (cld_one_band && b0 != cb_have) cld_load(b0);
-        }
+        if constexpr (CLD) cld_arrived();
         [[maybe_unused]] bool one_band = false;
         if constexpr (PF)
         {
-            const int b0 = rfl(pa.gpoint_bands[c0]) - 1, b1 = rfl(pa.gpoint_bands[gend-1]) - 1;
+            const int b0 = rfl(cband[8*c]), b1 = rfl(cband[8*c+1]);
             one_band = b0 == b1;
             if (one_band && b0 != cur_bnd) band_update(b0);
         }
@@ -2128,7 +2159,7 @@ gas_window_kernel(
                     if (!cld_one_band)              // (a chunk with a band boundary inside: not the rule)
                     {
                         while (ig + 1 > rfl(ia.cld_lims[2*cb+1])) ++cb;
-                        if (cb != cb_have) cld_load(cb);
+                        if (cb != cb_have) { cld_load(cb); cld_arrived(); }
                     }
                 }
                 if constexpr (MODE == 2)

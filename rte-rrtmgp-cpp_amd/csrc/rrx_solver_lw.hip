@@ -883,6 +883,8 @@ bool lw_fused_broadband(
     const bool v2_first = tuning().lw_variant != 14;
     if constexpr (sizeof(F) == 8)
     {
+        // (Round 4 measured six waves x six layers per column group -- 384-thread workgroups, three waves per SIMD, 168 VGPRs with
+        //  108-124 B of scratch: 4.2-4.7 ms against 2.7 for this form, profiles/r04_fp32_geometry_ab.txt.)
         if (launch_bb2<F,1,4,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;

@@ -106,6 +106,11 @@ def test_bench_starts_its_own_ranks():
     cmd = out.stdout.strip().split()
     assert "torch.distributed.run" in cmd and "--nproc-per-node=8" in cmd and "--master-addr" in cmd and "127.0.0.1" in cmd
     assert cmd[-5:] == ["--gpus", "8", "--steps", "3", "--dry-run"] and any(c.endswith("bench.py") for c in cmd)
+    # N > 1 defaults to BASELINE C4 as worded: 16 384 columns SHARDED over the GPUs (strong scaling)
+    assert out.stdout.splitlines()[0].startswith("# scaling strong: 16384 columns over 8 ranks: [2048, 2048")
+    weak = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "weak", "--dry-run"],
+                          capture_output=True, text=True, env=env, timeout=120)
+    assert weak.stdout.splitlines()[0].startswith("# scaling weak: 131072 columns over 8 ranks: [16384,")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
     assert one.returncode == 0 and "torch.distributed.run" not in one.stdout
 
@@ -120,6 +125,25 @@ def test_column_sharding_and_flux_gather(world, ncol, oracle_built):
     for p in procs: p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs)
     assert q.get(timeout=10) is True
+
+
+def test_all_sky_atmosphere_is_built_per_rank():
+    """bench.py --allsky builds only the rank's own columns: the same columns as the shard of the whole job."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    from rte_rrtmgp_cpp_amd import synthetic, sharding
+    full = synthetic.make_atmosphere(50, 20, nbnd_lw=2, nbnd_sw=2, seed=1234, clouds=True)
+    for world in (1, 3):
+        for rank in range(world):
+            args = argparse.Namespace(ncol=50, nlay=20, scaling="strong", allsky=True)
+            (s, e), part = bench.local_atmosphere(args, 2, rank, world)
+            ref = sharding.shard_atmosphere(full, rank, world)
+            assert part.ncol == e - s == ref.ncol
+            for k in ("lwp", "iwp", "rel", "dei", "t_lay", "p_lay", "t_sfc"):
+                assert np.array_equal(getattr(part, k), getattr(ref, k)), k
+            assert all(np.array_equal(part.vmr[n], ref.vmr[n]) for n in full.vmr)
+    assert (full.lwp > 0).any() and (full.lwp[:, 2] == 0).all()          # every third column is cloud-free
 
 
 def test_column_ranges_cover_everything():
