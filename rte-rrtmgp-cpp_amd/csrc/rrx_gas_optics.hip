@@ -807,6 +807,19 @@ __device__ __forceinline__ F interp1d(const F val, const F offset, const F delta
     const int idx = min(len-1, max(1, int(val0)+1));
     return table[idx-1] + frac * (table[idx] - table[idx-1]);
 }
+// the same in two steps, for one value looked up in many tables (the band Planck functions of all bands): position once, then per table
+template<typename F> struct Interp1dPos { F frac; int idx; };
+template<typename F>
+__device__ __forceinline__ Interp1dPos<F> interp1d_pos(const F val, const F offset, const F delta, const int len)
+{
+    const F val0 = (val - offset)/delta;
+    return Interp1dPos<F>{val0 - int(val0), min(len-1, max(1, int(val0)+1))};
+}
+template<typename F>
+__device__ __forceinline__ F interp1d_at(const Interp1dPos<F> p, const F* __restrict__ table)
+{
+    return table[p.idx-1] + p.frac * (table[p.idx] - table[p.idx-1]);
+}
 
 template<typename F>
 struct CellInterp
@@ -1746,6 +1759,28 @@ gas_window_kernel(
         is_last = ilay == nlay-1; is_sfc = ilay == pa.sfc_lay-1;
         t_lev = pa.tlev[idx];
     }
+    // Fractions form: the band-integrated Planck functions B_lay, B_lev of the bands of this workgroup's chunks, all at once, HERE --
+    // before the workgroup has a store in flight. Evaluated band by band at the top of each chunk (rounds 2-3) every band cost a
+    // memory round trip behind the stores of the chunk before (phase clocks: chunk prologue 104 k clocks per workgroup against 41 k
+    // in the SW form) and two fp64 divisions; now the table positions are found once and all bands' reads are in flight together.
+    if constexpr (PF)
+    {
+        const int b_first = rfl(cband[8*c_lo]), b_last = rfl(cband[8*(c_hi-1)+1]);
+        const size_t ncv_ = size_t(ncol)*(nlay+1);
+        const Interp1dPos<F> p_lay = interp1d_pos(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp);
+        const Interp1dPos<F> p_lev = interp1d_pos(t_lev, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp);
+        Interp1dPos<F> p_levp = p_lev;
+        if (is_last) p_levp = interp1d_pos(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp);
+        #pragma unroll 4
+        for (int ib=b_first; ib<=b_last; ++ib)
+        {
+            const F* tp = pa.totplnk + size_t(ib)*pa.nPlanckTemp;
+            const F bl = interp1d_at(p_lay, tp), bv = interp1d_at(p_lev, tp);
+            if (active) { pa.blay[idx + size_t(ib)*ncl] = bl; pa.blev[idx + size_t(ib)*ncv_] = bv; }
+            if (is_last && active) pa.blev[idx + ncol + size_t(ib)*ncv_] = interp1d_at(p_levp, tp);
+        }
+    }
+
 
     int cur_flav = -1, je_lo = 1;
     [[maybe_unused]] int ne_x = NEW;                                   // eta nodes of the current flavor's box that are in use
@@ -1839,6 +1874,19 @@ gas_window_kernel(
         RRX_GW_T(1)
         __syncthreads();                        // the previous chunk's readers are done with the windows
         RRX_GW_T(4)
+        // per-cell scalings of this chunk's contributors (registers). Their column amounts are requested NEXT TO the staging loads --
+        // behind the DMA issue in that form, ahead of the staging loads in the others -- so that both share one memory round trip
+        // (round 4; evaluated behind the staging they cost a round trip of their own behind the stores in flight: ~2 k clocks per chunk).
+        F sc[NCW]; int slo[NCW], shi[NCW];
+        auto chunk_scalings = [&]()
+        {
+            #pragma unroll
+            for (int i=0; i<NCW; ++i)
+            {
+                sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
+                if (i < n) { int koff_; sc[i] = minor_scaling(rfl(items[i])); item_meta(items, i, slo[i], shi[i], koff_); }
+            }
+        };
         // ---- stage the boxes: pairs (T, T+1) are adjacent words of the tables (temperature is their fastest dimension)
         if (RRX_GW_ABL != 2)
         {
@@ -1852,6 +1900,7 @@ gas_window_kernel(
             constexpr bool DMA = RRX_GW_LDSDMA && sizeof(F) == 8;
             // (the fp64 forms without fractions keep the DMA: with the staging registers they spill, and a spill reload at the top of a
             //  chunk waits behind every store in flight)
+            if constexpr (!DMA || PF) chunk_scalings();             // (register-staged forms: their loads go out ahead of the staging loads)
             if constexpr (RRX_GW_SPARSE && (PF || !DMA))
             {
                 // Sparse staging (round 3): a full box is 4 pressure x 4 eta nodes x 3 temperature pairs per g-point, what the cells of
@@ -1955,6 +2004,7 @@ gas_window_kernel(
                         glds(byte_off(kmin_u, unsigned((kg + koff)*tn + it_m + ie_m*ntemp)*SZ), Wmin + i*GCH*MBOX + tid);
                     }
             }
+            chunk_scalings();
             RRX_GW_T(2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the DMA writes have landed in LDS (the barrier below publishes them)
             RRX_GW_T(3)
@@ -2027,14 +2077,7 @@ gas_window_kernel(
             }
             }
         }
-        // per-cell scalings of this chunk's contributors (registers; independent of the staging above)
-        F sc[NCW]; int slo[NCW], shi[NCW];
-        #pragma unroll
-        for (int i=0; i<NCW; ++i)
-        {
-            sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
-            if (i < n) { int koff_; sc[i] = minor_scaling(rfl(items[i])); item_meta(items, i, slo[i], shi[i], koff_); }
-        }
+        if (RRX_GW_ABL == 2) chunk_scalings();
         RRX_GW_T(7)
         __syncthreads();
         RRX_GW_T(4)
@@ -2055,10 +2098,8 @@ gas_window_kernel(
             {
                 cur_bnd = ibnd;
                 const F* tp = pa.totplnk + size_t(ibnd)*pa.nPlanckTemp;
-                const F bl = interp1d(tl, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                const F bv = interp1d(t_lev, ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
-                if (active) { pa.blay[idx + size_t(ibnd)*ncl] = bl; pa.blev[idx + size_t(ibnd)*ncv] = bv; }
-                if (is_last && active) pa.blev[idx + ncol + size_t(ibnd)*ncv] = interp1d(pa.tlev[idx + ncol], ia.temp_ref_min, pa.totplnk_delta, pa.nPlanckTemp, tp);
+                // (B_lay, B_lev of every band of this workgroup's chunks were written at set-up; the surface layer's workgroups -- one
+                //  layer in 140 -- still look the surface terms up band by band)
                 if (is_sfc)
                 {
                     const F t_sfc = pa.tsfc[icol];
