@@ -20,7 +20,8 @@ class Cloud_optics_gpu : public Optical_props_gpu
         void cloud_optics(
                 const Array_gpu<Float,2>& clwp, const Array_gpu<Float,2>& ciwp,
                 const Array_gpu<Float,2>& reliq, const Array_gpu<Float,2>& deice,
-                Optical_props_2str_gpu& optical_props);
+                Optical_props_2str_gpu& optical_props,
+                const bool delta_scale = false);      // true: optical_props.delta_scale() folded into the same pass (one kernel, same bits)
     private:
         int liq_nsteps, ice_nsteps;
         Float radliq_lwr, radliq_upr, diamice_lwr, diamice_upr;

@@ -369,6 +369,12 @@ int rrx_cloud_optics_2str##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int 
         const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, \
         const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
         const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, F* ssa, F* g, void* stream); \
+/* rrx_cloud_optics_2str followed by rrx_delta_scale_2str_k (the reference driver's pair, Radiation_solver.cu:773-792) in one pass */ \
+int rrx_cloud_optics_2str_delta##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
+        F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
+        const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, \
+        const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
+        const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, F* ssa, F* g, void* stream); \
 int rrx_cloud_optics_1scl##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
         F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
         const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, \

@@ -349,33 +349,63 @@ __device__ __forceinline__ void cloud_from_table(const F cwp, const F re, const 
     else { tau = F(0.); taussa = F(0.); taussag = F(0.); }
 }
 
-template<typename F, bool TWOSTR>
-__global__ void cloud_optics_kernel(const size_t ncl, const int nsize_liq, const int nsize_ice,
+// One thread per (column, layer): water paths and particle sizes are read once, the table position (it depends on the size only) is
+// found once, and the thread walks over the bands (round 4; a thread per (cell, band) re-read the four inputs and redid the two
+// divisions nbnd times). DELTA: delta_scale_2str_k (optical_props_kernels.cu:103-136) applied to the values before they are stored --
+// the reference's cloud_optics() + delta_scale() pair (Radiation_solver.cu:773-792) in one pass, same expressions, same bits.
+template<typename F, bool TWOSTR, bool DELTA>
+__global__ void cloud_optics_kernel(const size_t ncl, const int nbnd, const int nsize_liq, const int nsize_ice,
         const F radliq_lwr, const F liq_step, const F diamice_lwr, const F ice_step,
         const F* __restrict__ lut_extliq, const F* __restrict__ lut_ssaliq, const F* __restrict__ lut_asyliq,
         const F* __restrict__ lut_extice, const F* __restrict__ lut_ssaice, const F* __restrict__ lut_asyice,
         const F* __restrict__ clwp, const F* __restrict__ ciwp, const F* __restrict__ reliq, const F* __restrict__ deice,
         F* __restrict__ tau, F* __restrict__ ssa, F* __restrict__ g)
 {
-    const int ibnd = blockIdx.y;
     const F eps = Lim<F>::eps();
+    const F eps_delta = Lim<F>::tiny()*F(3.);
     RRX_GRID_STRIDE(i, ncl)
     {
-        F lt, lts, ltsg, it, its, itsg;
-        cloud_from_table(clwp[i], reliq[i], nsize_liq, liq_step, radliq_lwr,
-                lut_extliq + size_t(ibnd)*nsize_liq, lut_ssaliq + size_t(ibnd)*nsize_liq, lut_asyliq + size_t(ibnd)*nsize_liq, lt, lts, ltsg);
-        cloud_from_table(ciwp[i], deice[i], nsize_ice, ice_step, diamice_lwr,
-                lut_extice + size_t(ibnd)*nsize_ice, lut_ssaice + size_t(ibnd)*nsize_ice, lut_asyice + size_t(ibnd)*nsize_ice, it, its, itsg);
-        const size_t o = i + size_t(ibnd)*ncl;
-        if constexpr (TWOSTR)
+        const F lw = clwp[i], iw = ciwp[i], rl = reliq[i], di = deice[i];
+        // /root/reference/src/Cloud_optics.cpp:72-107: position in the size tables
+        int il = 1, ii = 1; F fl = F(0.), fi = F(0.);
+        if (lw > F(0.)) { il = min(int((rl - radliq_lwr) / liq_step)+1, nsize_liq-1); fl = (rl - radliq_lwr) / liq_step - (il-1); }
+        if (iw > F(0.)) { ii = min(int((di - diamice_lwr) / ice_step)+1, nsize_ice-1); fi = (di - diamice_lwr) / ice_step - (ii-1); }
+        for (int ibnd=0; ibnd<nbnd; ++ibnd)
         {
-            const F t = lt + it, ts = lts + its, tsg = ltsg + itsg;
-            tau[o] = t;
-            ssa[o] = ts / max(t, eps);
-            g[o] = tsg / max(ts, eps);
+            F lt = F(0.), lts = F(0.), ltsg = F(0.), it = F(0.), its = F(0.), itsg = F(0.);
+            if (lw > F(0.))
+            {
+                const F* te = lut_extliq + size_t(ibnd)*nsize_liq; const F* ts = lut_ssaliq + size_t(ibnd)*nsize_liq; const F* ta = lut_asyliq + size_t(ibnd)*nsize_liq;
+                lt = lw * (te[il-1] + fl * (te[il] - te[il-1]));
+                lts = lt * (ts[il-1] + fl * (ts[il] - ts[il-1]));
+                ltsg = lts * (ta[il-1] + fl * (ta[il] - ta[il-1]));
+            }
+            if (iw > F(0.))
+            {
+                const F* te = lut_extice + size_t(ibnd)*nsize_ice; const F* ts = lut_ssaice + size_t(ibnd)*nsize_ice; const F* ta = lut_asyice + size_t(ibnd)*nsize_ice;
+                it = iw * (te[ii-1] + fi * (te[ii] - te[ii-1]));
+                its = it * (ts[ii-1] + fi * (ts[ii] - ts[ii-1]));
+                itsg = its * (ta[ii-1] + fi * (ta[ii] - ta[ii-1]));
+            }
+            const size_t o = i + size_t(ibnd)*ncl;
+            if constexpr (TWOSTR)
+            {
+                const F t = lt + it, tsc = lts + its, tsg = ltsg + itsg;
+                F tv = t, wv = tsc / max(t, eps), gv = tsg / max(tsc, eps);
+                if constexpr (DELTA)
+                {
+                    const F f = gv * gv;
+                    const F wf = wv * f;
+                    tv *= (F(1.) - wf);
+                    const F w2 = (wv - wf) / max(eps_delta, F(1.) - wf);
+                    gv = (gv - f) / max(eps_delta, F(1.) - f);
+                    wv = w2;
+                }
+                tau[o] = tv; ssa[o] = wv; g[o] = gv;
+            }
+            else
+                tau[o] = (lt - lts) + (it - its);
         }
-        else
-            tau[o] = (lt - lts) + (it - its);
     }
 }
 
@@ -643,15 +673,23 @@ int rrx_cloud_optics_2str##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int 
         const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
         const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, F* ssa, F* g, void* stream) \
 { RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
-  cloud_optics_kernel<F,true><<<dim3(std::min(grid1d(ncl), 1024), nbnd), 256, 0, ST>>>(ncl, nsize_liq, nsize_ice, \
+  cloud_optics_kernel<F,true,false><<<grid1d(ncl), 256, 0, ST>>>(ncl, nbnd, nsize_liq, nsize_ice, \
       radliq_lwr, (radliq_upr - radliq_lwr)/(nsize_liq - F(1.)), diamice_lwr, (diamice_upr - diamice_lwr)/(nsize_ice - F(1.)), \
       lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice, clwp, ciwp, reliq, deice, tau, ssa, g); RRX_CATCH("rrx_cloud_optics_2str") } \
+int rrx_cloud_optics_2str_delta##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
+        F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
+        const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
+        const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, F* ssa, F* g, void* stream) \
+{ RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
+  cloud_optics_kernel<F,true,true><<<grid1d(ncl), 256, 0, ST>>>(ncl, nbnd, nsize_liq, nsize_ice, \
+      radliq_lwr, (radliq_upr - radliq_lwr)/(nsize_liq - F(1.)), diamice_lwr, (diamice_upr - diamice_lwr)/(nsize_ice - F(1.)), \
+      lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice, clwp, ciwp, reliq, deice, tau, ssa, g); RRX_CATCH("rrx_cloud_optics_2str_delta") } \
 int rrx_cloud_optics_1scl##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int nsize_ice, \
         F radliq_lwr, F radliq_upr, F diamice_lwr, F diamice_upr, \
         const F* lut_extliq, const F* lut_ssaliq, const F* lut_asyliq, const F* lut_extice, const F* lut_ssaice, const F* lut_asyice, \
         const F* clwp, const F* ciwp, const F* reliq, const F* deice, F* tau, void* stream) \
 { RRX_TRY const size_t ncl = size_t(ncol)*nlay; \
-  cloud_optics_kernel<F,false><<<dim3(std::min(grid1d(ncl), 1024), nbnd), 256, 0, ST>>>(ncl, nsize_liq, nsize_ice, \
+  cloud_optics_kernel<F,false,false><<<grid1d(ncl), 256, 0, ST>>>(ncl, nbnd, nsize_liq, nsize_ice, \
       radliq_lwr, (radliq_upr - radliq_lwr)/(nsize_liq - F(1.)), diamice_lwr, (diamice_upr - diamice_lwr)/(nsize_ice - F(1.)), \
       lut_extliq, lut_ssaliq, lut_asyliq, lut_extice, lut_ssaice, lut_asyice, clwp, ciwp, reliq, deice, tau, (F*)nullptr, (F*)nullptr); RRX_CATCH("rrx_cloud_optics_1scl") } \
 int rrx_subset_cols##SFX(int ncol_full, int nrest, int col_s, int ncol_sub, const F* in, F* out, void* stream) \

@@ -421,11 +421,12 @@ class HipKernels:
         ngpt, ncol = toa_src.shape
         self._c("scaling_to_subset", ncol, ngpt, toa_src, tsi_scaling)
 
-    def cloud_optics_2str(self, lut, clwp, ciwp, reliq, deice):
+    def cloud_optics_2str(self, lut, clwp, ciwp, reliq, deice, delta_scale=False):
+        """delta_scale: cloud_optics followed by delta_scale_2str_k in one pass (the same bits)."""
         nlay, ncol = clwp.shape
         nbnd = lut["lut_extliq"].shape[0]
         tau = self.empty((nbnd, nlay, ncol)); ssa = self.empty((nbnd, nlay, ncol)); g = self.empty((nbnd, nlay, ncol))
-        self._c("cloud_optics_2str", ncol, nlay, nbnd, lut["nsize_liq"], lut["nsize_ice"],
+        self._c("cloud_optics_2str_delta" if delta_scale else "cloud_optics_2str", ncol, nlay, nbnd, lut["nsize_liq"], lut["nsize_ice"],
                 float(lut["radliq_lwr"]), float(lut["radliq_upr"]), float(lut["diamice_lwr"]), float(lut["diamice_upr"]),
                 lut["lut_extliq"], lut["lut_ssaliq"], lut["lut_asyliq"], lut["lut_extice"], lut["lut_ssaice"], lut["lut_asyice"],
                 clwp, ciwp, reliq, deice, tau, ssa, g)

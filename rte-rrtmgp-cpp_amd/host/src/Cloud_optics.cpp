@@ -31,8 +31,17 @@ Cloud_optics_gpu::Cloud_optics_gpu(
 void Cloud_optics_gpu::cloud_optics(
         const Array_gpu<Float,2>& clwp, const Array_gpu<Float,2>& ciwp,
         const Array_gpu<Float,2>& reliq, const Array_gpu<Float,2>& deice,
-        Optical_props_2str_gpu& op)
+        Optical_props_2str_gpu& op, const bool delta_scale)
 {
+    // delta_scale: op.delta_scale() folded into the pass that produces the values (same expressions, same bits)
+    if (delta_scale)
+    {
+        RRX_CALL(rrx_cloud_optics_2str_delta, clwp.dim(1), clwp.dim(2), this->get_nband(), liq_nsteps, ice_nsteps,
+                 radliq_lwr, radliq_upr, diamice_lwr, diamice_upr,
+                 lut_extliq_gpu.ptr(), lut_ssaliq_gpu.ptr(), lut_asyliq_gpu.ptr(), lut_extice_gpu.ptr(), lut_ssaice_gpu.ptr(), lut_asyice_gpu.ptr(),
+                 clwp.ptr(), ciwp.ptr(), reliq.ptr(), deice.ptr(), op.get_tau().ptr(), op.get_ssa().ptr(), op.get_g().ptr());
+        return;
+    }
     RRX_CALL(rrx_cloud_optics_2str, clwp.dim(1), clwp.dim(2), this->get_nband(), liq_nsteps, ice_nsteps,
              radliq_lwr, radliq_upr, diamice_lwr, diamice_upr,
              lut_extliq_gpu.ptr(), lut_ssaliq_gpu.ptr(), lut_asyliq_gpu.ptr(), lut_extice_gpu.ptr(), lut_ssaice_gpu.ptr(), lut_asyice_gpu.ptr(),

@@ -416,9 +416,9 @@ void Radiation_solver_shortwave::solve_gpu(
         //  the add_to() of Radiation_solver.cu:788-791 folded into the producer)
         if (switch_cloud_optics)
         {
-            cloud_optics_gpu->cloud_optics(sub2(lwp, n_lay), sub2(iwp, n_lay), sub2(rel, n_lay), sub2(dei, n_lay), *ws.cloud_optical_props);
-            if (switch_delta_cloud)
-                ws.cloud_optical_props->delta_scale();
+            // (delta_scale() of Radiation_solver.cu:785 rides along in the same kernel)
+            cloud_optics_gpu->cloud_optics(sub2(lwp, n_lay), sub2(iwp, n_lay), sub2(rel, n_lay), sub2(dei, n_lay), *ws.cloud_optical_props,
+                                           switch_delta_cloud);
         }
         Array_gpu<Float,2> toa_src_s({n_in, n_gpt});
         kdist_gpu->gas_optics(p_lay_s, p_lev_s, t_lay_s, gas_concs_subset, ws.optical_props, toa_src_s, col_dry_s,

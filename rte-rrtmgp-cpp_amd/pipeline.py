@@ -360,8 +360,7 @@ class ResidentSolver:
                 gbuf = None if (self.g_zero and self.do_broadband) else buf["g"]
                 cld = None
                 if self.cloud_luts is not None:     # Radiation_solver.cu:773-792
-                    cld = be.cloud_optics_2str(self.cloud_luts[1], atm.lwp, atm.iwp, atm.rel, atm.dei)
-                    be.delta_scale_2str_k(*cld)
+                    cld = be.cloud_optics_2str(self.cloud_luts[1], atm.lwp, atm.iwp, atm.rel, atm.dei, delta_scale=True)
                 if self.direct:
                     be.gas_optics_sw_direct(kd, atm.p_lay, atm.t_lay, col_gas, col_dry, buf["tau"], buf["ssa"], gbuf, by_band=cld if fuse else None)
                 else:

@@ -153,3 +153,19 @@ def test_toa_source_equals_spread_then_scale(dt, hip_f64, hip_f32):
         b = be.toa_source(ncol, src, tsi)
         assert np.array_equal(be.to_numpy(a), be.to_numpy(b))
         assert np.array_equal(be.to_numpy(a), (be.to_numpy(src)[:, None] * be.to_numpy(tsi)[None, :]).astype(be.np_dtype))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_cloud_optics_with_delta_scaling_in_one_pass(dt, hip_f64, hip_f32):
+    """rrx_cloud_optics_2str_delta = rrx_cloud_optics_2str followed by rrx_delta_scale_2str_k (Radiation_solver.cu:773-792), bit for bit."""
+    be = hip_f64 if dt == "f64" else hip_f32
+    nbnd = 5
+    atm0 = synthetic.make_atmosphere(96, 30, nbnd_lw=nbnd, nbnd_sw=nbnd, clouds=True, seed=4)
+    lut = be.upload_lut({k: (v.astype(be.np_dtype) if isinstance(v, np.ndarray) else v) for k, v in synthetic.make_cloud_lut(nbnd, "sw").items()})
+    atm = pipeline.upload_atmosphere(be, atm0.astype(be.np_dtype))
+    two = be.cloud_optics_2str(lut, atm.lwp, atm.iwp, atm.rel, atm.dei)
+    be.delta_scale_2str_k(*two)
+    one = be.cloud_optics_2str(lut, atm.lwp, atm.iwp, atm.rel, atm.dei, delta_scale=True)
+    assert float(be.to_numpy(two[0]).max()) > 0
+    for a, b in zip(two, one):
+        assert np.array_equal(be.to_numpy(a), be.to_numpy(b))
