@@ -31,6 +31,9 @@ class Gas_concs_gpu
         void set_vmr(const std::string& name, const Array<Float,2>& data);
         void set_vmr(const std::string& name, const Array_gpu<Float,2>& data);
         Bool exists(const std::string& name) const;
+        // (not in the reference) the same gases with their per-column fields gathered through a column index of n_out entries
+        // (rrx_gather_cols: columns in another order and / or padded); scalars and profiles are shared as they are
+        Gas_concs_gpu gathered(const Array_gpu<int,1>& perm, const int n_col, const int n_out) const;
     private:
         std::map<std::string, Array_gpu<Float,2>> gas_concs_map;
 };

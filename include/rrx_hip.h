@@ -60,6 +60,8 @@ int rrx_stream_destroy(void* stream);
    caller created itself -- call it from the thread that made the solver calls, before destroying the stream). A block larger than
    RRX_WORKSPACE_KEEP bytes (environment, default 32 GiB) is returned at the end of the call that used it. */
 int rrx_release_workspace(void* stream);
+/* perm[i] = min(i, ncol-1), i < ncol + npad: the identity order, padded (see rrx_sort_columns) */
+int rrx_identity_columns(int ncol, int npad, int* perm, void* stream);
 unsigned long long rrx_workspace_bytes(void* stream);
 /* include/Array.h:311-350,579-622 (Array_gpu::subset / subset_kernel): N-D block gather, singleton dimensions are
    broadcast. sub_dims/strides/starts/spread are HOST arrays of length ndim (<= 7); strides in elements, starts 0-based. */
@@ -385,7 +387,18 @@ int rrx_cloud_optics_1scl##SFX(int ncol, int nlay, int nbnd, int nsize_liq, int 
 int rrx_subset_cols##SFX(int ncol_full, int nrest, int col_s, int ncol_sub, const F* in, F* out, void* stream); \
 /* same for arrays whose LAST dimension is the column, e.g. emis_sfc(nbnd,ncol) */ \
 int rrx_subset_lastdim##SFX(int n1, int col_s, int ncol_sub, const F* in, F* out, void* stream); \
-int rrx_fill##SFX(unsigned long long n, F value, F* arr, void* stream);
+int rrx_fill##SFX(unsigned long long n, F value, F* arr, void* stream); \
+/* ---- column ordering of the product chain (csrc/rrx_columns.hip; no counterpart in the reference library): columns are independent, so \
+   a solve may process them in any order. perm (ncol + npad ints on the device) is a gather index: rrx_sort_columns = ascending order of \
+   key(ncol) (the surface pressure: neighbouring columns then share LUT boxes in the windowed gas optics), its last npad entries repeat \
+   the last column (padding to a multiple of 16 columns); rrx_column_spread sets flag = 1 where a run of `block` consecutive columns \
+   spans more than threshold x its mean. gather: out(i, r) = in(perm[i], r), i < nout, column FIRST (fastest) dimension; gather_lastdim: \
+   out(b, i) = in(b, perm[i]) for (n1, ncol) arrays; scatter: out(perm[i], r) = in(i, r), i < n (arrays of ncol_src / ncol_dst columns). */ \
+int rrx_sort_columns##SFX(int ncol, const F* key, int npad, int* perm, void* stream); \
+int rrx_column_spread##SFX(int ncol, const F* key, int block, F threshold, int* flag, void* stream); \
+int rrx_gather_cols##SFX(int nout, unsigned long long nrest, const int* perm, int ncol_in, const F* in, F* out, void* stream); \
+int rrx_scatter_cols##SFX(int n, unsigned long long nrest, const int* perm, int ncol_src, const F* in, int ncol_dst, F* out, void* stream); \
+int rrx_gather_lastdim##SFX(int n1, int nout, const int* perm, const F* in, F* out, void* stream);
 
 RRX_DECLARE(double, _f64)
 RRX_DECLARE(float, _f32)

@@ -266,17 +266,27 @@ namespace rrx
 
 namespace rrx
 {
-    // Number of g-point ranges the one-kernel broadband solvers split their loop into when `groups` column groups alone would
-    // leave most of the chip idle (few columns per GPU: BASELINE C4 on 8 GPUs is 2 048 columns each). Each range sums its
-    // g-points in order into its own (nlev, ncol) partial; a second kernel adds the partials in range order, so the result is
-    // deterministic (it differs from the unsplit sum only in the association of the additions).
-    inline int broadband_gsplit(const int groups, const int ngpt)
+    // Number of g-point ranges the one-kernel broadband solvers split their loop into. `groups` workgroups of equal length run on
+    // `slots` resident places (256 CUs x workgroups per CU), i.e. in ceil(groups / slots) rounds: few columns per GPU (BASELINE C4
+    // on 8 GPUs is 2 048 each: 128 groups) leave most of the chip idle, and a column count just above a multiple of the slots
+    // (16 385 columns: 1 025 groups) pays a whole extra round for its last workgroup (+20 %, round 4). Splitting the g-point loop
+    // into n ranges makes n times as many workgroups of 1/n the length: the cost ceil(groups n / slots) / n is minimised over
+    // n = 1, 2, 4, 8, 16 (a split must pay at least 1 % per doubling: the partial sums are written and added by a second kernel).
+    // Each range sums its g-points in order into its own (nlev, ncol) partial; the partials are added in range order, so the
+    // result is deterministic (it differs from the unsplit sum only in the association of the additions).
+    inline int broadband_gsplit(const int groups, const int ngpt, const int slots = 512)
     {
         const Tuning& t = tuning();
         if (t.bb_gsplit >= 1) return std::min(t.bb_gsplit, ngpt);
-        int n = 1;
-        while (groups*n < t.bb_min_groups && n < 16 && 2*n*4 <= ngpt) n *= 2;
-        return n;
+        if (t.bb_min_groups <= 1) return 1;                               // (rrx_set_broadband_min_groups(1): never split)
+        int best = 1;
+        double best_cost = double(ceil_div(groups, slots));
+        for (int n = 2, k = 1; n <= 16 && n*4 <= ngpt; n *= 2, ++k)
+        {
+            const double cost = double(ceil_div((long long)groups*n, slots)) / n * (1.0 + 0.01*k);
+            if (cost < best_cost) { best_cost = cost; best = n; }
+        }
+        return best;
     }
 }
 

@@ -841,7 +841,7 @@ bool launch_bb2(
     const int need = ceil_div(nlay+1, (64/CLT)*W);
     if (need > ((CLT == 16) ? 9 : 5)) return false;
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
-    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
+    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt, (NW > 4) ? 256 : 512));      // (one or two workgroups per CU)
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     StreamScratch scratch(st);

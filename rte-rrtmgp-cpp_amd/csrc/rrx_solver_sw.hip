@@ -771,7 +771,7 @@ bool launch_scan_bb(hipStream_t st,
     const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31)
                      && (sizeof(F) == 8 ? g == nullptr : (V == 1 && CLT == 16));
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
-    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt));
+    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt, (NW > 4) ? 256 : 512));      // (one or two workgroups per CU)
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     StreamScratch scratch(st);

@@ -76,3 +76,16 @@ void Gas_concs_gpu::set_vmr(const std::string& name, const Array_gpu<Float,2>& d
 }
 
 Bool Gas_concs_gpu::exists(const std::string& name) const { return gas_concs_map.count(name) != 0; }
+
+Gas_concs_gpu Gas_concs_gpu::gathered(const Array_gpu<int,1>& perm, const int n_col, const int n_out) const
+{
+    Gas_concs_gpu out;
+    for (const auto& g : gas_concs_map)
+    {
+        if (g.second.dim(1) != n_col || n_col == 1) { out.gas_concs_map.emplace(g.first, g.second); continue; }
+        Array_gpu<Float,2> a({n_out, g.second.dim(2)});
+        RRX_CALL(rrx_gather_cols, n_out, (unsigned long long)g.second.dim(2), perm.ptr(), n_col, g.second.ptr(), a.ptr());
+        out.gas_concs_map.emplace(g.first, std::move(a));
+    }
+    return out;
+}

@@ -167,6 +167,75 @@ namespace
         for (int s=1; s<=n_col; s+=n_col_block) b.emplace_back(s, std::min(n_col_block, n_col - s + 1));
         return b;
     }
+
+    // ---- column order of a solve (include_test/Radiation_solver.h: set_column_sorting / set_column_padding) ----
+    // A gather index over the caller's columns: sorted by surface pressure and / or padded to a multiple of 16 by repeating the last one.
+    struct Column_order
+    {
+        int n_col = 0, n_out = 0;
+        Array_gpu<int,1> perm;
+        bool active() const { return n_out > 0; }
+        // (col, n2) -> (n_out, n2); an absent (empty) array stays absent
+        Array_gpu<Float,2> in2(const Array_gpu<Float,2>& a) const
+        {
+            if (a.size() == 0) return Array_gpu<Float,2>();
+            Array_gpu<Float,2> o({n_out, a.dim(2)});
+            RRX_CALL(rrx_gather_cols, n_out, (unsigned long long)a.dim(2), perm.ptr(), n_col, a.ptr(), o.ptr());
+            return o;
+        }
+        Array_gpu<Float,1> in1(const Array_gpu<Float,1>& a) const
+        {
+            if (a.size() == 0) return Array_gpu<Float,1>();
+            Array_gpu<Float,1> o({n_out});
+            RRX_CALL(rrx_gather_cols, n_out, 1ull, perm.ptr(), n_col, a.ptr(), o.ptr());
+            return o;
+        }
+        // (n1, col) -> (n1, n_out)
+        Array_gpu<Float,2> in_last(const Array_gpu<Float,2>& a) const
+        {
+            if (a.size() == 0) return Array_gpu<Float,2>();
+            Array_gpu<Float,2> o({a.dim(1), n_out});
+            RRX_CALL(rrx_gather_lastdim, a.dim(1), n_out, perm.ptr(), a.ptr(), o.ptr());
+            return o;
+        }
+        // results of the reordered solve back into the caller's arrays (first n_col entries of perm: the permutation proper)
+        template<int N> void out(Array_gpu<Float,N>& dst, const Array_gpu<Float,N>& src) const
+        {
+            if (src.size() == 0) return;
+            std::array<int,N> d; d[0] = n_col; unsigned long long rest = 1;
+            for (int i=1; i<N; ++i) { d[i] = src.dim(i+1); rest *= (unsigned long long)src.dim(i+1); }
+            if (dst.size() == 0) dst.set_dims(d);
+            RRX_CALL(rrx_scatter_cols, n_col, rest, perm.ptr(), n_out, src.ptr(), n_col, dst.ptr());
+        }
+    };
+
+    // Should this solve reorder its columns, and how? `sort_decided` caches the automatic decision of the solver object.
+    Column_order column_order(const int mode, int& sort_decided, const bool pad, const Array_gpu<Float,2>& p_lev, const Bool top_at_1)
+    {
+        Column_order co;
+        const int n_col = p_lev.dim(1), n_lev = p_lev.dim(2);
+        const Float* p_sfc = p_lev.ptr() + size_t(top_at_1 ? n_lev-1 : 0)*n_col;
+        bool sort = mode == 1;
+        if (mode < 0 && n_col >= 256)
+        {
+            if (sort_decided < 0)
+            {
+                Array_gpu<int,1> flag({1});
+                RRX_CALL(rrx_column_spread, n_col, p_sfc, 256, Float(0.2), flag.ptr());
+                int h = 0;
+                rrx_host::check(rrx_memcpy_d2h_stream(&h, flag.ptr(), sizeof(int), rrx_host::current_stream()));     // (synchronises: once per solver)
+                sort_decided = h ? 1 : 0;
+            }
+            sort = sort_decided == 1;
+        }
+        const int n_pad = (pad && n_col > 16 && n_col % 16 != 0) ? 16 - n_col % 16 : 0;
+        if (!sort && n_pad == 0) return co;
+        co.n_col = n_col; co.n_out = n_col + n_pad;
+        co.perm.set_dims({co.n_out});
+        if (sort) RRX_CALL(rrx_sort_columns, n_col, p_sfc, n_pad, co.perm.ptr());
+        else rrx_host::check(rrx_identity_columns(n_col, n_pad, co.perm.ptr(), rrx_host::current_stream()));
+        return co;
+    }
 }
 
 
@@ -223,6 +292,27 @@ void Radiation_solver_longwave::solve_gpu(
     const Bool top_at_1 = (vertical_ordering < 0) ? Bool(p_lay({1, 1}) < p_lay({1, n_lay})) : Bool(vertical_ordering == 1);
     if (switch_cloud_optics && !cloud_optics_gpu) throw std::runtime_error("cloud optics requested but no cloud coefficients loaded");
     const bool broadband = broadband_solvers && !switch_output_bnd_fluxes;
+
+    // columns in another order / on a padded count: gather the inputs, solve, scatter the fluxes back (see the header)
+    if (!reordered_call && !switch_output_optical && switch_fluxes)
+    {
+        const Column_order co = column_order(column_sorting, sort_decided, column_padding, p_lev, top_at_1);
+        if (co.active())
+        {
+            const Gas_concs_gpu gases = gas_concs.gathered(co.perm, n_col, co.n_out);
+            Array_gpu<Float,3> no3a, no3b, no3c; Array_gpu<Float,2> no2;
+            Array_gpu<Float,2> up, dn, net; Array_gpu<Float,3> bup, bdn, bnet;
+            up.set_dims({co.n_out, n_lev}); dn.set_dims({co.n_out, n_lev}); net.set_dims({co.n_out, n_lev});
+            if (switch_output_bnd_fluxes) { bup.set_dims({co.n_out, n_lev, n_bnd}); bdn.set_dims({co.n_out, n_lev, n_bnd}); bnet.set_dims({co.n_out, n_lev, n_bnd}); }
+            struct Guard { bool& f; Guard(bool& f_) : f(f_) { f = true; } ~Guard() { f = false; } } guard(reordered_call);
+            this->solve_gpu(switch_fluxes, switch_cloud_optics, switch_output_optical, switch_output_bnd_fluxes, gases,
+                            co.in2(p_lay), co.in2(p_lev), co.in2(t_lay), co.in2(t_lev), co.in2(col_dry), co.in1(t_sfc), co.in_last(emis_sfc),
+                            co.in2(lwp), co.in2(iwp), co.in2(rel), co.in2(dei), no3a, no3b, no3c, no2, up, dn, net, bup, bdn, bnet);
+            co.out(lw_flux_up, up); co.out(lw_flux_dn, dn); co.out(lw_flux_net, net);
+            if (switch_output_bnd_fluxes) { co.out(lw_bnd_flux_up, bup); co.out(lw_bnd_flux_dn, bdn); co.out(lw_bnd_flux_net, bnet); }
+            return;
+        }
+    }
 
     auto prepare = [&](std::shared_ptr<Workspace>& ws, const int n)
     {
@@ -372,6 +462,33 @@ void Radiation_solver_shortwave::solve_gpu(
     if (switch_cloud_optics && !cloud_optics_gpu) throw std::runtime_error("cloud optics requested but no cloud coefficients loaded");
     if (switch_aerosol_optics && !aerosol_optics_gpu) throw std::runtime_error("aerosol optics requested but no aerosol coefficients loaded");
     const bool broadband = broadband_solvers && !switch_output_bnd_fluxes;
+
+    // columns in another order / on a padded count: gather the inputs, solve, scatter the fluxes back (see the header)
+    if (!reordered_call && !switch_output_optical && switch_fluxes)
+    {
+        const Column_order co = column_order(column_sorting, sort_decided, column_padding, p_lev, top_at_1);
+        if (co.active())
+        {
+            const Gas_concs_gpu gases = gas_concs.gathered(co.perm, n_col, co.n_out);
+            Aerosol_concs_gpu aerosols = aerosol_concs.gathered(co.perm, n_col, co.n_out);
+            Array_gpu<Float,3> no3a, no3b, no3c; Array_gpu<Float,2> no2;
+            Array_gpu<Float,2> up, dn, dir, net; Array_gpu<Float,3> bup, bdn, bdir, bnet;
+            up.set_dims({co.n_out, n_lev}); dn.set_dims({co.n_out, n_lev}); dir.set_dims({co.n_out, n_lev}); net.set_dims({co.n_out, n_lev});
+            if (switch_output_bnd_fluxes)
+            { bup.set_dims({co.n_out, n_lev, n_bnd}); bdn.set_dims({co.n_out, n_lev, n_bnd}); bdir.set_dims({co.n_out, n_lev, n_bnd}); bnet.set_dims({co.n_out, n_lev, n_bnd}); }
+            struct Guard { bool& f; Guard(bool& f_) : f(f_) { f = true; } ~Guard() { f = false; } } guard(reordered_call);
+            this->solve_gpu(switch_fluxes, switch_cloud_optics, switch_aerosol_optics, switch_output_optical, switch_output_bnd_fluxes,
+                            switch_delta_cloud, switch_delta_aerosol, gases,
+                            co.in2(p_lay), co.in2(p_lev), co.in2(t_lay), co.in2(t_lev), co.in2(col_dry),
+                            co.in_last(sfc_alb_dir), co.in_last(sfc_alb_dif), co.in1(tsi_scaling), co.in1(mu0),
+                            co.in2(lwp), co.in2(iwp), co.in2(rel), co.in2(dei), co.in2(rh), aerosols,
+                            no3a, no3b, no3c, no2, up, dn, dir, net, bup, bdn, bdir, bnet);
+            co.out(sw_flux_up, up); co.out(sw_flux_dn, dn); co.out(sw_flux_dn_dir, dir); co.out(sw_flux_net, net);
+            if (switch_output_bnd_fluxes)
+            { co.out(sw_bnd_flux_up, bup); co.out(sw_bnd_flux_dn, bdn); co.out(sw_bnd_flux_dn_dir, bdir); co.out(sw_bnd_flux_net, bnet); }
+            return;
+        }
+    }
 
     auto prepare = [&](std::shared_ptr<Workspace>& ws, const int n)
     {

@@ -342,7 +342,8 @@ void solve_radiation(int argc, char** argv)
         {"broadband-solvers", { true,  "Sum g-points inside the solvers (no per-g-point fluxes; off with --output-bnd-fluxes)." }},
         {"heating-rates"    , { false, "Output layer heating rates lw_heating_rate / sw_heating_rate (K/s)." }},
         {"async"            , { false, "Host-model mode: vertical ordering read once, solves enqueued without synchronising." }},
-        {"sort-columns"     , { true,  "Solve the columns in order of surface pressure where neighbours differ much (outputs keep the input order)." }}};
+        {"sort-columns"     , { true,  "Solve the columns in order of surface pressure where neighbours differ much (outputs keep the input order)." }},
+        {"device-sort-columns", { false, "Leave the ordering to the solvers: sorted and padded on the device inside solve_gpu (Radiation_solver::set_column_sorting(1)) instead of on the host before the upload." }}};
 
     if (parse_command_line_options(command_line_options, argc, argv))
         return;
@@ -360,7 +361,8 @@ void solve_radiation(int argc, char** argv)
     const bool switch_broadband         = command_line_options.at("broadband-solvers").first;
     const bool switch_heating_rates     = command_line_options.at("heating-rates"    ).first;
     const bool switch_async             = command_line_options.at("async"            ).first;
-    const bool switch_sort_columns      = command_line_options.at("sort-columns"     ).first;
+    const bool switch_device_sort       = command_line_options.at("device-sort-columns").first;
+    const bool switch_sort_columns      = command_line_options.at("sort-columns"     ).first && !switch_device_sort;
 
     Status::print_message("Solver settings:");
     for (const auto& option : command_line_options)
@@ -476,6 +478,10 @@ void solve_radiation(int argc, char** argv)
         Radiation_solver_longwave rad_lw(gas_concs_gpu, "coefficients_lw.nc", switch_cloud_optics ? "cloud_coefficients_lw.nc" : "");
         rad_lw.set_column_block(col_block);
         rad_lw.set_broadband_solvers(switch_broadband);
+        // (--no-sort-columns: the file's order and column count exactly; otherwise the solver pads to a multiple of 16 columns and,
+        //  with --device-sort-columns, orders them itself)
+        rad_lw.set_column_sorting(switch_device_sort ? 1 : (switch_sort_columns ? -1 : 0));
+        rad_lw.set_column_padding(switch_sort_columns || switch_device_sort);
         if (switch_async) rad_lw.set_vertical_ordering(p_lay({1, 1}) < p_lay({1, n_lay}) ? 1 : 0);    // known on the host: no read-backs per solve
 
         const int n_bnd_lw = rad_lw.get_n_bnd_gpu();
@@ -549,6 +555,8 @@ void solve_radiation(int argc, char** argv)
                 "coefficients_sw.nc", "cloud_coefficients_sw.nc", "aerosol_optics.nc");
         rad_sw.set_column_block(col_block);
         rad_sw.set_broadband_solvers(switch_broadband);
+        rad_sw.set_column_sorting(switch_device_sort ? 1 : (switch_sort_columns ? -1 : 0));
+        rad_sw.set_column_padding(switch_sort_columns || switch_device_sort);
         if (switch_async) rad_sw.set_vertical_ordering(p_lay({1, 1}) < p_lay({1, n_lay}) ? 1 : 0);
 
         const int n_bnd_sw = rad_sw.get_n_bnd_gpu();

@@ -212,6 +212,18 @@ class ResidentSolver:
             else:
                 sort_columns = False
         self.sort_columns = bool(sort_columns) and str(sort_columns) != "0"
+        # Padding (round 4): the step runs on a multiple of 16 columns -- the rows of the (col, lay, gpt) intermediates then start on
+        # 128-B lines (16 385 columns cost 20 % more than 16 384 otherwise); the extra columns repeat the last one and are dropped
+        # when the fluxes go back to the caller's order. One gather index serves both (built once, not per step, and
+        # applied to an explicit list of per-column fields): refresh_column_order() rebuilds it when the host model's pressures
+        # have changed enough to matter.
+        pad = bool(int(os.environ.get("RRX_PAD_COLUMNS", "1"))) and atm.ncol > 16 and atm.ncol % 16 != 0
+        self.npad = (16 - atm.ncol % 16) if pad else 0
+        self.ncol_caller = atm.ncol
+        self.perm = None
+        self.atm = atm
+        if self.sort_columns or self.npad:
+            self.refresh_column_order()
         # overlap: LW and SW chains are independent, so they can run on two HIP streams and share the chip (the gather-
         # bound gas-optics kernels of one chain fill in next to the HBM-bound solver of the other)
         self.overlap = overlap
@@ -225,7 +237,7 @@ class ResidentSolver:
         self.direct = bool(int(os.environ.get("RRX_DIRECT", "1")))     # interpolation state recomputed inside its consumers
         # broadband mode: Planck fractions + band Planck functions, sources formed inside the LW solver ("Planck-lite" chain)
         self.lite = self.direct and do_broadband and bool(int(os.environ.get("RRX_LITE", "1")))
-        ncol, nlay = atm.ncol, atm.nlay
+        ncol, nlay = atm.ncol + self.npad, atm.nlay              # columns of a step (padded)
         ng_l, ng_s = kd_lw.ngpt, kd_sw.ngpt
         e = be.empty
         self.col_dry = e((nlay, ncol))
@@ -240,8 +252,8 @@ class ResidentSolver:
             self.lw.update(gpt_up=e((ng_l, nlay+1, ncol)), gpt_dn=e((ng_l, nlay+1, ncol)))
             self.sw.update(gpt_up=e((ng_s, nlay+1, ncol)), gpt_dn=e((ng_s, nlay+1, ncol)), gpt_dir=e((ng_s, nlay+1, ncol)))
         # packed broadband outputs: LW up/dn/net + SW up/dn/dir/net  (7, nlev, ncol) -> one all-gather
-        self.fluxes = e((7, nlay+1, ncol))
-        self.fluxes_sorted = e((7, nlay+1, ncol)) if self.sort_columns else None
+        self.fluxes = e((7, nlay+1, atm.ncol))
+        self.fluxes_sorted = e((7, nlay+1, ncol)) if self.perm is not None else None
         self.weights = be.asarray(np.ascontiguousarray(GAUSS_WTS[0, :1]))
         self.gauss_Ds = be.asarray(GAUSS_DS)
         # secants and the band -> g-point expansion of emissivity / albedos: buffers allocated once, the launches themselves are
@@ -263,29 +275,44 @@ class ResidentSolver:
                 out[s].append(a.elapsed_time(b))
         return {s: float(np.mean(v)) for s, v in out.items() if v}
 
-    def _sorted_atmosphere(self):
-        """The atmosphere with its columns in ascending order of surface pressure, and the permutation (sorted -> original)."""
-        from .synthetic import Atmosphere
+    # per-column fields of an Atmosphere and the axis their column index sits on (everything else is shared by all columns)
+    _COLUMN_FIELDS = {"p_lay": -1, "p_lev": -1, "t_lay": -1, "t_lev": -1, "t_sfc": 0, "mu0": 0, "tsi_scaling": 0,
+                      "emis_sfc": 0, "sfc_alb_dir": 0, "sfc_alb_dif": 0, "lwp": -1, "iwp": -1, "rel": -1, "dei": -1, "rh": -1}
+
+    def refresh_column_order(self):
+        """(Re)build the gather index of a step: ascending surface pressure when sorting, the caller's order otherwise, padded with
+        repeats of its last entry. Call it again when the pressures have changed enough to matter; the index is reused otherwise."""
+        torch = self.torch
         a = self.atm
-        perm = self.torch.argsort(a.p_lev[-1 if a.top_at_1 else 0])
-        sel = lambda t: t.index_select(t.dim() - 1, perm) if (t is not None and t.dim() >= 1 and t.shape[-1] == a.ncol) else t
+        if self.sort_columns:
+            perm = torch.argsort(a.p_lev[-1 if a.top_at_1 else 0])
+        else:
+            perm = torch.arange(a.ncol, device=a.p_lev.device)
+        if self.npad:
+            perm = torch.cat([perm, perm[-1:].expand(self.npad)])
+        self.perm = perm.contiguous()
+
+    def _gathered_atmosphere(self):
+        """The atmosphere with its columns in the order (and count) of self.perm."""
+        from .synthetic import Atmosphere
+        a, perm = self.atm, self.perm
         out = {}
         for k, v in a.__dict__.items():
-            if k in ("emis_sfc", "sfc_alb_dir", "sfc_alb_dif"):          # stored (ncol, nbnd)
-                out[k] = v.index_select(0, perm)
-            elif isinstance(v, dict):
-                out[k] = {n: sel(t) for n, t in v.items()}
-            elif hasattr(v, "index_select"):
-                out[k] = sel(v)
+            if k == "ncol":
+                out[k] = int(perm.numel())
+            elif k in self._COLUMN_FIELDS and v is not None:
+                out[k] = v.index_select(v.dim() - 1 if self._COLUMN_FIELDS[k] < 0 else 0, perm)
+            elif isinstance(v, dict):      # vmr / aermr: (nlay, ncol) fields are per column, profiles (nlay,) and scalars are shared
+                out[k] = {n: (t.index_select(1, perm) if (hasattr(t, "dim") and t.dim() == 2) else t) for n, t in v.items()}
             else:
                 out[k] = v
-        return Atmosphere(**out), perm
+        return Atmosphere(**out)
 
     def step(self):
         be, atm = self.be, self.atm
-        perm = None
-        if self.sort_columns:
-            atm, perm = self._sorted_atmosphere()
+        perm = self.perm
+        if perm is not None:
+            atm = self._gathered_atmosphere()
         if self.overlap and self.col_dry2 is None:
             self.col_dry2 = be.empty(tuple(self.col_dry.shape))
         rec = None
@@ -389,7 +416,8 @@ class ResidentSolver:
                 ctx.__exit__(None, None, None)
         if self.overlap:
             main.wait_stream(self.streams[0]); main.wait_stream(self.streams[1])
-        if perm is not None:
-            self.fluxes.index_copy_(2, perm, F)          # back to the caller's column order
+        if perm is not None:                              # back to the caller's column order (padding columns dropped)
+            n = self.ncol_caller
+            self.fluxes.index_copy_(2, perm[:n], F[:, :, :n])
             F = self.fluxes
         return F

@@ -328,6 +328,15 @@ def test_driver_solves_differing_columns_in_order_of_surface_pressure(tmp_path, 
             assert cases.rel_err(out[k], ref[k]) <= tol, k
             n += 1
     assert n >= 16
+    # the same inside the solvers (Radiation_solver_*::set_column_sorting(1): device-side radix sort by surface pressure, inputs gathered,
+    # 300 columns padded to 304, fluxes scattered back) instead of on the host before the upload
+    assert run_driver(d, *flags, "--device-sort-columns") == 0
+    _, dev = read_output(d)
+    assert "order of surface pressure" not in capfd.readouterr().out
+    for k in ref:
+        if k.endswith(("_flux_up", "_flux_dn", "_flux_net", "_flux_dn_dir", "_heating_rate")):
+            tol = 1e-6 if k.endswith("_heating_rate") else (1e-7 if k.startswith("sw_") else 1e-11)
+            assert dev[k].shape == ref[k].shape and cases.rel_err(dev[k], ref[k]) <= tol, k
     # alike columns: nothing to sort
     atm2 = synthetic.make_atmosphere(300, 60, nbnd_lw=KW["nbnd"], nbnd_sw=KW["nbnd"], seed=11)
     synthetic_files.write_input(os.path.join(d, "rte_rrtmgp_input.nc"), atm2, KW["nbnd"], KW["nbnd"])

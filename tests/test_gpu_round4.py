@@ -169,3 +169,33 @@ def test_cloud_optics_with_delta_scaling_in_one_pass(dt, hip_f64, hip_f32):
     assert float(be.to_numpy(two[0]).max()) > 0
     for a, b in zip(two, one):
         assert np.array_equal(be.to_numpy(a), be.to_numpy(b))
+
+
+@pytest.mark.parametrize("spread", [0.0, 0.35], ids=["alike", "differing"])
+def test_resident_solver_pads_and_orders_columns(spread, hip_f64, monkeypatch):
+    """ResidentSolver runs its step on a multiple of 16 columns (padding by repeats of the last column) and, where neighbouring
+    columns differ, in order of surface pressure -- one cached gather index for both; the caller sees its own columns in its own
+    order. Against the same solver with padding and sorting switched off."""
+    be = hip_f64
+    ncol, nlay = 273, 40
+    kw = dict(ngpt=64, nbnd=4, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
+    kl, ks = be.upload_kdist(synthetic.make_kdist("lw", **kw)), be.upload_kdist(synthetic.make_kdist("sw", **kw))
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=4, nbnd_sw=4, seed=5)
+    if spread > 0:
+        rng = np.random.default_rng(8)
+        f = rng.uniform(1 - spread, 1 + spread, ncol)
+        atm0.p_lay = np.ascontiguousarray(atm0.p_lay * f); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * f)
+    atm = pipeline.upload_atmosphere(be, atm0)
+    monkeypatch.setenv("RRX_PAD_COLUMNS", "0")
+    plain = pipeline.ResidentSolver(be, kl, ks, atm, do_broadband=True, sort_columns="0")
+    assert plain.perm is None
+    ref = be.to_numpy(plain.step()).copy()
+    monkeypatch.setenv("RRX_PAD_COLUMNS", "1")
+    solver = pipeline.ResidentSolver(be, kl, ks, atm, do_broadband=True, sort_columns="auto")
+    assert solver.npad == 15 and solver.perm.numel() == 288 and solver.sort_columns == (spread > 0)
+    got = be.to_numpy(solver.step())
+    assert got.shape == ref.shape == (7, nlay+1, ncol)
+    # (a column meets other neighbours in the sorted run: windowed or gather gas optics, 1e-15 apart, amplified by the SW solver)
+    assert cases.rel_err(got[:3], ref[:3]) <= 1e-11 and cases.rel_err(got[3:], ref[3:]) <= 1e-7
+    again = be.to_numpy(solver.step())
+    assert np.array_equal(got, again)
