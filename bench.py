@@ -251,6 +251,9 @@ def main():
                     help="column heterogeneity: pressures x U(1-s,1+s), temperatures + U(-30s,30s) K per column (default 0 = SURVEY 8(d)'s workload)")
     ap.add_argument("--sort-columns", default=None, choices=["auto", "0", "1"],
                     help="process the columns in ascending order of surface pressure (auto: when neighbouring columns differ; see pipeline.ResidentSolver)")
+    ap.add_argument("--driver", default="python", choices=["python", "cxx"],
+                    help="python: pipeline.ResidentSolver (every buffer allocated once, the kernels called through the C ABI); cxx: the C++ host "
+                         "classes -- Radiation_solver_longwave / _shortwave::solve_gpu, the reference's class structure -- on the same kernels")
     ap.add_argument("--allsky", action="store_true",
                     help="BASELINE's all-sky flow (C5): cloud optics added by band after the gas optics, delta-scaled in SW; not the headline workload")
     args = ap.parse_args()
@@ -311,8 +314,14 @@ def main():
         ntot = global_columns(a, world)
         (col_s, col_e), atm0 = local_atmosphere(a, nbnd, rank, world)
         atm = pipeline.upload_atmosphere(be, atm0.astype(np_dtype))
-        solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts,
-                                         sort_columns=args.sort_columns)
+        if args.driver == "cxx":
+            from rte_rrtmgp_cpp_amd import cxx_driver
+            luts0 = (synthetic.make_cloud_lut(nbnd, "lw"), synthetic.make_cloud_lut(nbnd, "sw")) if args.allsky else None
+            sort_mode = {None: -1, "auto": -1, "0": 0, "1": 1}[args.sort_columns]
+            solver = cxx_driver.CxxDriver(be, kd_lw0, kd_sw0, atm, luts0, column_block=max(atm.ncol, 16), broadband=args.broadband, sort_mode=sort_mode)
+        else:
+            solver = pipeline.ResidentSolver(be, kd_lw, kd_sw, atm, do_broadband=args.broadband, overlap=args.overlap, cloud_luts=cloud_luts,
+                                             sort_columns=args.sort_columns)
         do_gather = world > 1 and not args.no_gather
         gatherer = sharding.FluxGatherer(ntot, solver.fluxes, pipelined=not args.sync_gather) if do_gather else None
 
@@ -327,7 +336,7 @@ def main():
             gatherer.finish()
         # one untimed step with the windowed gas optics' hand-back census switched on (it synchronises the stream per launch)
         handed = None
-        if primary and rank == 0 and be.lib.has("rrx_gas_window_stats"):
+        if primary and rank == 0 and be.lib.has("rrx_gas_window_stats") and args.driver == "python":
             import ctypes
             os.environ["RRX_GW_STATS"] = "1"
             be.lib.cdll.rrx_gas_window_stats(None, None, 1)
@@ -340,7 +349,7 @@ def main():
             be.lib.cdll.rrx_gas_window_stats(ctypes.byref(c1), ctypes.byref(c2), 1)
             if c2.value > 0:
                 handed = {"handed_back": int(c1.value), "workgroups": int(c2.value), "frac": round(c1.value / c2.value, 4)}
-        if primary:
+        if primary and args.driver == "python":
             solver.enable_stage_events(args.steps)
 
         if world > 1:
@@ -372,7 +381,21 @@ def main():
                  "ms_per_step": round(o["dt"] / args.steps * 1e3, 3), "columns_per_gpu": o["ncol_local"], "columns_total": o["ntot"]}
         del o
 
-    if rank == 0:
+    if rank == 0 and args.driver == "cxx":
+        # the C++ host classes enqueue a whole solve per call: no per-stage events from here; the kernels are the ones of the default
+        # driver, whose line carries the roofline
+        out = {"metric": "columns/sec (LW+SW full solve, 140 lay x 256 gpt)", "value": round(ntot * args.steps / dt, 1), "unit": "columns/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"C4 synthetic {ncol_local} columns/GPU ({ntot} in total) x {args.nlay} layers x {args.ngpt} g-points, "
+                                      f"LW+SW {'all-sky' if args.allsky else 'clear-sky'}, RCEMIP profile, synthetic k-distribution (real shapes)",
+                          "driver": "C++ host classes (Radiation_solver_longwave / _shortwave::solve_gpu) through librte_rrtmgp_hip.so",
+                          "columns_per_gpu": ncol_local, "columns_total": ntot, "nlay": args.nlay, "ngpt": args.ngpt},
+               "roofline": None, "finite": bool(torch.isfinite(solver.fluxes).all().item())}
+        if other is not None:
+            out["other_scaling"] = other
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
         S = np_dtype().itemsize
         ms = solver.stage_ms()
         words = algo_words(args.nlay, args.ngpt, nbnd, args.broadband, solver.g_zero and args.broadband, solver.lite)

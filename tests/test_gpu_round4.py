@@ -199,3 +199,31 @@ def test_resident_solver_pads_and_orders_columns(spread, hip_f64, monkeypatch):
     assert cases.rel_err(got[:3], ref[:3]) <= 1e-11 and cases.rel_err(got[3:], ref[3:]) <= 1e-7
     again = be.to_numpy(solver.step())
     assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("clouds", [False, True], ids=["clear", "allsky"])
+def test_cxx_host_classes_driven_from_python(clouds, hip_f64):
+    """bench.py --driver cxx: Radiation_solver_longwave / _shortwave::solve_gpu (the reference's class structure) through the C entry
+    points of cxx_driver_api.cpp on device arrays torch owns, against pipeline.ResidentSolver on the same kernels. 273 columns with
+    a pressure spread: the solvers sort and pad the columns on the device and hand the fluxes back in the caller's order."""
+    from rte_rrtmgp_cpp_amd import cxx_driver
+    be = hip_f64
+    ncol, nlay, nbnd = 273, 40, 4
+    kw = dict(ngpt=64, nbnd=nbnd, npres=20, nflav=4, nminor_lower=9, nminor_upper=5)
+    kl0, ks0 = synthetic.make_kdist("lw", **kw), synthetic.make_kdist("sw", **kw)
+    atm0 = synthetic.make_atmosphere(ncol, nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=5, clouds=clouds)
+    rng = np.random.default_rng(8)
+    f = rng.uniform(0.65, 1.35, ncol)
+    atm0.p_lay = np.ascontiguousarray(atm0.p_lay * f); atm0.p_lev = np.ascontiguousarray(atm0.p_lev * f)
+    atm = pipeline.upload_atmosphere(be, atm0)
+    luts0 = (synthetic.make_cloud_lut(nbnd, "lw"), synthetic.make_cloud_lut(nbnd, "sw")) if clouds else None
+    luts = tuple(be.upload_lut(l) for l in luts0) if clouds else None
+    ref = be.to_numpy(pipeline.ResidentSolver(be, be.upload_kdist(kl0), be.upload_kdist(ks0), atm, do_broadband=True, cloud_luts=luts).step()).copy()
+    drv = cxx_driver.CxxDriver(be, kl0, ks0, atm, luts0, column_block=ncol)
+    try:
+        got = be.to_numpy(drv.step()).copy()
+        again = be.to_numpy(drv.step())
+    finally:
+        drv.close()
+    assert np.array_equal(got, again)
+    assert cases.rel_err(got[:3], ref[:3]) <= 1e-11 and cases.rel_err(got[3:], ref[3:]) <= 1e-7
