@@ -23,5 +23,10 @@ class Rte_lw_gpu
                 const std::unique_ptr<Optical_props_arry_gpu>& ops,
                 const Array_gpu<Float,2> arr_in,
                 Array_gpu<Float,2>& arr_out);
+    private:
+        // Gauss-Jacobi secants and weights on the device, uploaded once per object and angle count (an upload per call is a host
+        // copy the stream is synchronised for: the solver launch then waits for the gas optics to finish before it is even enqueued)
+        Array_gpu<Float,2> gauss_Ds_gpu, gauss_wts_gpu;
+        int gauss_angles_cached = 0;
 };
 #endif

@@ -42,9 +42,15 @@ void Rte_lw_gpu::rte_lw(
     Array_gpu<Float,2> sfc_emis_gpt({ncol, ngpt});
     expand_and_transpose(optical_props, sfc_emis, sfc_emis_gpt);
 
-    const Array_gpu<Float,2> gauss_Ds(Array<Float,2>(gauss_Ds_v, {max_gauss_pts, max_gauss_pts}));
-    const Array<Float,2> gauss_wts(gauss_wts_v, {max_gauss_pts, max_gauss_pts});
-    const Array_gpu<Float,2> gauss_wts_subset(gauss_wts.subset({{ {1, n_gauss_angles}, {n_gauss_angles, n_gauss_angles} }}));
+    if (gauss_angles_cached != n_gauss_angles)
+    {
+        gauss_Ds_gpu = Array_gpu<Float,2>(Array<Float,2>(gauss_Ds_v, {max_gauss_pts, max_gauss_pts}));
+        const Array<Float,2> gauss_wts(gauss_wts_v, {max_gauss_pts, max_gauss_pts});
+        gauss_wts_gpu = Array_gpu<Float,2>(gauss_wts.subset({{ {1, n_gauss_angles}, {n_gauss_angles, n_gauss_angles} }}));
+        gauss_angles_cached = n_gauss_angles;
+    }
+    const Array_gpu<Float,2>& gauss_Ds = gauss_Ds_gpu;
+    const Array_gpu<Float,2>& gauss_wts_subset = gauss_wts_gpu;
 
     Array_gpu<Float,3> secants({ncol, ngpt, n_gauss_angles});
     Rte_solver_kernels_cuda::lw_secants_array(ncol, ngpt, n_gauss_angles, max_gauss_pts, gauss_Ds.ptr(), secants.ptr());

@@ -6,6 +6,7 @@
 #include "Radiation_solver.h"
 #include "Netcdf_interface.h"
 #include "subset_kernels_cuda.h"
+#include "fluxes_kernels_cuda.h"
 
 namespace
 {
@@ -379,7 +380,19 @@ void Radiation_solver_longwave::solve_gpu(
             continue;
 
         constexpr int n_ang = 1;
-        Array_gpu<Float,2> emis_s = emis_sfc.subset({{ {1, n_bnd}, {col_s, col_e} }});
+        Array_gpu<Float,2> emis_s = whole ? Array_gpu<Float,2>(const_cast<Float*>(emis_sfc.ptr()), {n_bnd, n_in}) : emis_sfc.subset({{ {1, n_bnd}, {col_s, col_e} }});
+        if (whole && broadband && !switch_output_bnd_fluxes)
+        {
+            // one block in broadband mode: the solver writes the caller's flux arrays, the net flux follows in place (no block
+            // workspace, no copies: Fluxes_broadband_gpu::reduce + get_from_subset of the general path are 7 passes over the fluxes)
+            if (lw_flux_up.size() == 0) lw_flux_up.set_dims({n_col, n_lev});
+            if (lw_flux_dn.size() == 0) lw_flux_dn.set_dims({n_col, n_lev});
+            if (lw_flux_net.size() == 0) lw_flux_net.set_dims({n_col, n_lev});
+            Array_gpu<Float,3> up3(lw_flux_up.ptr(), {n_col, n_lev, 1}), dn3(lw_flux_dn.ptr(), {n_col, n_lev, 1});
+            rte_lw.rte_lw(ws.optical_props, top_at_1, *ws.sources, emis_s, Array_gpu<Float,2>(), up3, dn3, n_ang);
+            Fluxes_kernels_cuda::net_broadband_precalc(n_col, n_lev, lw_flux_dn.ptr(), lw_flux_up.ptr(), lw_flux_net.ptr());
+            continue;
+        }
         rte_lw.rte_lw(ws.optical_props, top_at_1, *ws.sources, emis_s, Array_gpu<Float,2>(), ws.gpt_flux_up, ws.gpt_flux_dn, n_ang);
 
         Fluxes_broadband_gpu fluxes(n_in, n_lev);
@@ -563,8 +576,18 @@ void Radiation_solver_shortwave::solve_gpu(
         if (!switch_fluxes)
             continue;
 
-        rte_sw.rte_sw(ws.optical_props, top_at_1, sub1(mu0), toa_src_s,
-                sfc_alb_dir.subset({{ {1, n_bnd}, {col_s, col_e} }}), sfc_alb_dif.subset({{ {1, n_bnd}, {col_s, col_e} }}),
+        auto sub_last = [&](const Array_gpu<Float,2>& a) { return whole ? Array_gpu<Float,2>(const_cast<Float*>(a.ptr()), {n_bnd, n_in})
+                                                                          : a.subset({{ {1, n_bnd}, {col_s, col_e} }}); };
+        if (whole && broadband && !switch_output_bnd_fluxes)
+        {
+            // one block in broadband mode: the solver writes the caller's flux arrays, the net flux follows in place
+            for (Array_gpu<Float,2>* a : {&sw_flux_up, &sw_flux_dn, &sw_flux_dn_dir, &sw_flux_net}) if (a->size() == 0) a->set_dims({n_col, n_lev});
+            Array_gpu<Float,3> up3(sw_flux_up.ptr(), {n_col, n_lev, 1}), dn3(sw_flux_dn.ptr(), {n_col, n_lev, 1}), dir3(sw_flux_dn_dir.ptr(), {n_col, n_lev, 1});
+            rte_sw.rte_sw(ws.optical_props, top_at_1, sub1(mu0), toa_src_s, sub_last(sfc_alb_dir), sub_last(sfc_alb_dif), Array_gpu<Float,2>(), up3, dn3, dir3);
+            Fluxes_kernels_cuda::net_broadband_precalc(n_col, n_lev, sw_flux_dn.ptr(), sw_flux_up.ptr(), sw_flux_net.ptr());
+            continue;
+        }
+        rte_sw.rte_sw(ws.optical_props, top_at_1, sub1(mu0), toa_src_s, sub_last(sfc_alb_dir), sub_last(sfc_alb_dif),
                 Array_gpu<Float,2>(), ws.gpt_flux_up, ws.gpt_flux_dn, ws.gpt_flux_dn_dir);
 
         Fluxes_broadband_gpu fluxes(n_in, n_lev);
