@@ -839,7 +839,7 @@ bool launch_bb2(
     if (size_t(ncol)*(nlay+1) >= (size_t(1) << 31)) return false;          // 32-bit element offsets inside a g-point slab
     const int groups = ceil_div(ncol, (NW/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
-    if (need > ((CLT == 16) ? 9 : 5)) return false;
+    if (need > ((CLT == 16 || W == 8) ? 9 : 5)) return false;
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
     const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt, (NW > 4) ? 256 : 512));      // (one or two workgroups per CU)
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
@@ -860,6 +860,7 @@ bool launch_bb2(
         break; }
     do {
     if constexpr (CLT == 16) { RRX_LW_B2(2) RRX_LW_B2(4) RRX_LW_B2(6) RRX_LW_B2(9) }
+    else if constexpr (W == 8) { RRX_LW_B2(5) RRX_LW_B2(7) RRX_LW_B2(9) }      // (288 ... 319 / 447 / 575 layers: eight waves of 8 x 8 lanes)
     else                     { RRX_LW_B2(2) RRX_LW_B2(3) RRX_LW_B2(5) }
     } while (false);
     if (nsplit > 1)      // (out_up, out_dn lie behind each other in the scratch block)
@@ -889,8 +890,15 @@ bool lw_fused_broadband(
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;
         // 144 ... 287 layers: eight wavefronts per column group
-        return launch_bb2<F,1,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
-                                         blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
+        if (launch_bb2<F,1,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                      blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        // 288 ... 575 layers (round 4: RCEMIP's default is 256 levels, LES grids with a background profile on top exceed 288): the same
+        // eight waves with 8 x 8 lanes -- 64 levels per wave at nine layers per lane, 64-B rows (the other half of each 128-B line
+        // belongs to the next column group: twice the L2 fetches, on a kernel that stands at a quarter of the HBM roof). Beyond that
+        // the one-thread-per-column kernels take over.
+        return launch_bb2<F,1,8,8,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                        blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn);
     }
     else
     {
@@ -919,6 +927,11 @@ bool lw_fused_broadband(
         if (ncol % 2 == 0 &&
             launch_bb2<F,2,8,16,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
                                       blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
+            return true;
+        // 288 ... 575 layers: eight waves of 8 x 8 lanes (see fp64)
+        if (ncol % 2 == 0 &&
+            launch_bb2<F,2,8,8,LITE>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,
+                                     blay, blev, gpoint_bands, sfc_emis, sfc_src, inc_flux, flux_up, flux_dn))
             return true;
         // odd column counts: one column per lane
         return launch_bb2<F,1,4,16,LITE,8>(st, pre, ncol, nlay, ngpt, top_at_1, secants, weights, tau, lay_source, lev_source,

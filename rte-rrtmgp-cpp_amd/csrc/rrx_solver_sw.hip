@@ -755,15 +755,15 @@ template<typename Fn> void with_flag(const bool flag, Fn&& f) { if (flag) f(std:
 
 // Fused broadband form. W waves per column group, CLT column lanes per wave (two column groups per workgroup); false when the
 // columns are taller than the form's largest K (the caller tries the next form).
-template<typename F, int V, int W = 2, int CLT = 8>
+template<typename F, int V, int W = 2, int CLT = 8, int NWG = (W > 2 ? 2*W : 4)>
 bool launch_scan_bb(hipStream_t st,
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* tau, const F* ssa, const F* g, const F* mu0, const F* sfc_alb_dir, const F* sfc_alb_dif,
         const F* inc_flux_dir, const F* inc_flux_dif, F* flux_up, F* flux_dn, F* flux_dir)
 {
-    constexpr int NW = (W > 2) ? 2*W : 4;                 // wavefronts per workgroup: two column groups
+    constexpr int NW = NWG;                               // wavefronts per workgroup: two column groups (one where NWG == W)
     constexpr int KMAX = (CLT == 16) ? 12 : (W > 2 ? 9 : 12);       // (8 x 8 lanes, W = 4: nine layers per lane fill the LDS of a CU)
-    const int groups = ceil_div(ncol, 2*CLT*V);
+    const int groups = ceil_div(ncol, (NW/W)*CLT*V);
     const int need = ceil_div(nlay+1, (64/CLT)*W);
     if (need > KMAX) return false;
     // pipelined loads: fp64 without g array only (with it 27 prefetched doubles spill); fp32 in the one-column-per-lane geometry
@@ -785,7 +785,8 @@ bool launch_scan_bb(hipStream_t st,
         with_flag(g == nullptr, [&](auto gz) { with_flag(pre, [&](auto pr) { with_flag(nsplit > 1, [&](auto gs)
         {
             constexpr bool GZ = decltype(gz)::value, GS = decltype(gs)::value;
-            constexpr bool PRE = decltype(pr)::value && (GZ || sizeof(F) == 4);
+            // (the pipelined form exists where launch_scan_bb may pick it: fp64 without g array, fp32 with one column per lane)
+            constexpr bool PRE = decltype(pr)::value && (sizeof(F) == 8 ? GZ : (V == 1 && CLT == 16));
             sw_2stream_scan_kernel<F,V,KK,W,true,GZ,PRE,GS,NW,CLT><<<grid, 64*NW, 0, st>>>(
                 ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif, inc_flux_dir, inc_flux_dif,
                 up, dn, dr, sync_waves, gper);
@@ -796,6 +797,7 @@ bool launch_scan_bb(hipStream_t st,
     {
         if constexpr (CLT == 16) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
         else if constexpr (W == 2) { RRX_SW_K(2) RRX_SW_K(4) RRX_SW_K(6) RRX_SW_K(9) RRX_SW_K(12) }
+        else if constexpr (W == 8) { RRX_SW_K(5) RRX_SW_K(7) RRX_SW_K(9) }      // (288 ... 319 / 447 / 575 layers)
         else { RRX_SW_K(9) }
     } while (false);
 #undef RRX_SW_K
@@ -846,6 +848,12 @@ int sw_solver_2stream_impl(
         if (ncol % VBB == 0 &&
             launch_scan_bb<F,VBB,4>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                     inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+            return 0;
+        // 288 ... 575 layers (round 4): eight wavefronts on ONE column group per workgroup (64 levels per wave at nine layers per lane;
+        // the row segments are 64 B with no partner group in the workgroup: twice the L2 fetches, on a kernel bound by fp64 issue)
+        if (ncol % VBB == 0 &&
+            launch_scan_bb<F,VBB,8,8,8>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                        inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
             return 0;
     }
 

@@ -118,10 +118,11 @@ def test_full_solve_matches_oracle(kind, ncol, nlay, top_at_1, clouds, hip_f64, 
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
-@pytest.mark.parametrize("ncol,nlay,top_at_1", [(24, 200, False), (17, 287, True)])
+@pytest.mark.parametrize("ncol,nlay,top_at_1", [(24, 200, False), (17, 287, True), (17, 288, False), (10, 400, True), (9, 575, False), (8, 576, False)])
 def test_tall_columns_in_broadband_mode_match_oracle(kind, ncol, nlay, top_at_1, hip_f64, oracle_f64):
     """144 ... 287 layers (an LES grid with a background profile on top): the fused broadband solvers with eight wavefronts per
-    column group (LW) / four (SW), product chain (fractions form) against the oracle in do_broadband mode."""
+    column group (LW) / four (SW); 288 ... 575 layers (round 4): eight wavefronts of 8 x 8 lanes in both; 576: the one-thread-per-
+    column forms. Product chain (fractions form) against the oracle in do_broadband mode."""
     h, o = _solve_both(hip_f64, oracle_f64, kind, ncol, nlay, top_at_1, False, do_broadband=True)
     for k in ("flux_up", "flux_dn", "flux_net"):
         e = cases.rel_err(h[k], o[k])
@@ -131,9 +132,10 @@ def test_tall_columns_in_broadband_mode_match_oracle(kind, ncol, nlay, top_at_1,
 @pytest.mark.parametrize("kind", ["lw", "sw"])
 def test_tall_columns_fp32_broadband_mode(kind, hip_f32, oracle_f32):
     """The same tall-column kernels in the RTE_USE_SP build (two columns per lane), against the fp32 oracle."""
-    h, o = _solve_both(hip_f32, oracle_f32, kind, 24, 230, False, False, do_broadband=True)
-    for k in ("flux_up", "flux_dn", "flux_net"):
-        assert cases.rel_err(h[k], o[k], floor=1e-2) <= (1e-3 if kind == "sw" else 2e-4), k     # (fp32 two-stream scans: as test_c5_fp32_…)
+    for ncol, nlay in ((24, 230), (12, 400)):
+        h, o = _solve_both(hip_f32, oracle_f32, kind, ncol, nlay, False, False, do_broadband=True)
+        for k in ("flux_up", "flux_dn", "flux_net"):
+            assert cases.rel_err(h[k], o[k], floor=1e-2) <= (1e-3 if kind == "sw" else 2e-4), (k, nlay)     # (fp32 two-stream scans: as test_c5_fp32_…)
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])

@@ -107,7 +107,7 @@ def test_workspace_belongs_to_its_stream(hip_f64):
     lib = be.lib.cdll
     lib.rrx_workspace_bytes.restype = ctypes.c_ulonglong
     rng = np.random.default_rng(9)
-    ngpt, nlay, ncol = 4, 300, 48                      # 300 layers: beyond every fused tiling -> workspace forms
+    ngpt, nlay, ncol = 4, 600, 48                      # 600 layers: beyond every fused tiling (575) -> workspace forms
     tau, ssa, g, lay, lev, e2, mu0 = _random_columns(rng, ngpt, nlay, ncol)
     up = be.asarray
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

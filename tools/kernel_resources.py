@@ -33,7 +33,7 @@ for f in files:
     for n, d in zip(names, dem):
         d = re.sub(r"^void ", "", d); d = d.replace("(anonymous namespace)::", ""); d = re.sub(r"\(.*$", "", d)
         table.append((d, rows[n]))
-    for d, r in sorted(table):
+    for d, r in sorted(table, key=lambda x: x[0]):
         lines.append("%-132s %5d %5d %6d %8d %4d %7d" % (d[:132], r.get("VGPRs", -1), r.get("AGPRs", -1), r.get("VGPRs Spill", -1),
                      r.get("ScratchSize [bytes/lane]", -1), r.get("Occupancy [waves/SIMD]", -1), r.get("LDS Size [bytes/block]", -1)))
 open(out_path, "w").write("\n".join(lines) + "\n")
