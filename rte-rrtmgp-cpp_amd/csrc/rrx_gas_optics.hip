@@ -376,7 +376,11 @@ tau_absorption_kernel(
     // (todo_geom 1: the handed-back workgroup was 256 columns of one layer, see gas_window_geometry)
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*blockDim.x + threadIdx.x;
     const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
-    if (icol >= ncol || ilay >= nlay) continue;
+    // (control flow stays uniform across the workgroup here: every thread reaches the loop latch and its barriers; a per-thread
+    //  `continue` past them was a divergent barrier -- ADVICE r03)
+    const bool cell_ok = icol < ncol && ilay < nlay;
+    if (cell_ok)
+    {
 
     const size_t ncl = size_t(ncol)*nlay;
     const size_t idx = icol + size_t(ilay)*ncol;
@@ -740,6 +744,7 @@ tau_absorption_kernel(
         }
     }
     }   // regime passes
+    }   // cell_ok
     }   // entries
 }
 
@@ -1150,7 +1155,11 @@ planck_fraction_kernel(
     }
     const int icol = todo_geom ? (blk_x*4 + int(threadIdx.y))*64 + int(threadIdx.x) : blk_x*64 + threadIdx.x;
     const int ilay = todo_geom ? blk_y : blk_y*blockDim.y + threadIdx.y;
-    if (icol >= ncol || ilay >= nlay) continue;
+    // (control flow stays uniform across the workgroup here: every thread reaches the loop latch and its barriers; a per-thread
+    //  `continue` past them was a divergent barrier -- ADVICE r03)
+    const bool cell_ok = icol < ncol && ilay < nlay;
+    if (cell_ok)
+    {
     const size_t ncl = size_t(ncol)*nlay;
     const size_t ncv = size_t(ncol)*(nlay+1);
     const size_t idx = icol + size_t(ilay)*ncol;
@@ -1240,6 +1249,7 @@ planck_fraction_kernel(
         }
         ig = ge;
     }
+    }   // cell_ok
     }   // entries
 }
 

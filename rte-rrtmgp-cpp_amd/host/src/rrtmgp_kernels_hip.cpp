@@ -1,7 +1,8 @@
 // librrtmgp_kernels_hip.so -- the reference's CPU boundary (include/rrtmgp_kernels.h, the 19 bind(C) names of
 // /root/reference/include/rrtmgp_kernels.h:32-289) on top of the MI355X device layer librrx_hip.so.
 //
-// Every entry point: host arrays -> device (stream-ordered pool, one stream per calling thread) -> the rrx_* launcher that
+// Every entry point: host arrays -> device (stream-ordered pool, ONE stream per calling thread, created at the thread's first call
+// and destroyed -- with the workspace block the any-nlay solver forms keep on it -- when the thread ends) -> the rrx_* launcher that
 // replaces the Fortran kernel -> outputs back to the host -> wait. It is a compatibility surface for code written against
 // the CPU API (the reference's own src/*.cpp link against it unchanged); the fast path keeps its data resident and uses
 // include/rrx_hip.h or the _gpu classes directly. No CPU fallback: without a GPU every call throws.
@@ -17,16 +18,25 @@ namespace
     [[noreturn]] void fail(const std::string& what) { throw std::runtime_error("rrtmgp_kernels_hip: " + what); }
     void ok(const int status) { if (status != 0) fail(rrx_last_error()); }
 
+    // the calling thread's stream (round 4, ADVICE r03: a stream per CALL left the solvers' cached workspace block behind a dead
+    // handle each time; rrx_stream_destroy now hands that block back, and the stream lives as long as its thread)
+    struct ThreadStream
+    {
+        void* s = nullptr;
+        ThreadStream() { ok(rrx_stream_create(&s)); }
+        ~ThreadStream() { if (s != nullptr) rrx_stream_destroy(s); }
+    };
+    void* thread_stream() { static thread_local ThreadStream t; return t.s; }
+
     // Device staging of one call. Buffers go back to the pool in stream order when the call ends (also on an exception).
     class Stage
     {
         public:
-            Stage() { ok(rrx_stream_create(&stream_)); }
+            Stage() : stream_(thread_stream()) {}
             ~Stage()
             {
                 for (void* p : bufs_) rrx_free_async(p, stream_);
                 rrx_synchronize(stream_);
-                rrx_stream_destroy(stream_);
             }
             Stage(const Stage&) = delete;
             Stage& operator=(const Stage&) = delete;
@@ -283,9 +293,17 @@ void rte_lw_solver_noscat(
     if (do_broadband) { d_bup = S.out(flux_up_loc, nlev); d_bdn = S.out(flux_dn_loc, nlev); }
     else              { d_up = S.out(gpt_flux_up, nlev*size_t(ngpt)); d_dn = S.out(gpt_flux_dn, nlev*size_t(ngpt)); }
     const Float* d_sjac = do_jacobians ? S.in(sfc_source_jac, ng) : nullptr;
-    Float* d_jac = do_jacobians ? S.out(gpt_flux_up_jac, nlev*size_t(ngpt)) : nullptr;
+    // the Jacobian output is sized like the live flux output (src/Rte_lw.cpp:181): (ncol, nlev, 1) in broadband mode -- the per-g-point
+    // Jacobian then stays on the device and its g-point sum goes back (copying nlev*ngpt values overran the caller's array)
+    Float *d_jac = nullptr, *d_jac_bb = nullptr;
+    if (do_jacobians)
+    {
+        if (do_broadband) { d_jac = S.alloc<Float>(nlev*size_t(ngpt)); d_jac_bb = S.out(gpt_flux_up_jac, nlev); }
+        else d_jac = S.out(gpt_flux_up_jac, nlev*size_t(ngpt));
+    }
     RRX_K(rrx_lw_solver_noscat, ncol, nlay, ngpt, top_at_1, n_quad_angs, d_sec, d_wts, d_tau, d_lay, d_lev, d_emis, d_src, d_inc,
           d_up, d_dn, do_broadband, d_bup, d_bdn, do_jacobians, d_sjac, d_jac);
+    if (d_jac_bb != nullptr) RRX_K(rrx_sum_broadband, ncol, nlay + 1, ngpt, d_jac, d_jac_bb);
     S.finish();
 }
 

@@ -227,3 +227,25 @@ def test_cxx_host_classes_driven_from_python(clouds, hip_f64):
         drv.close()
     assert np.array_equal(got, again)
     assert cases.rel_err(got[:3], ref[:3]) <= 1e-11 and cases.rel_err(got[3:], ref[3:]) <= 1e-7
+
+
+def test_cpu_boundary_broadband_jacobian_is_sized_like_the_fluxes():
+    """rte_lw_solver_noscat at the CPU boundary with do_broadband AND do_jacobians: the Jacobian comes back as one (ncol, nlev) array
+    -- the g-point sum -- like the fluxes (src/Rte_lw.cpp:181 sizes it so); nothing is written behind it."""
+    import cpu_boundary
+    from rte_rrtmgp_cpp_amd._ffi import BoolArg
+    b = cpu_boundary.HipCpuBoundary(np.float64)
+    rng = np.random.default_rng(12)
+    ngpt, nlay, ncol = 5, 30, 20
+    tau, _, _, lay, lev, e2, _ = _random_columns(rng, ngpt, nlay, ncol)
+    sec = np.full((1, ngpt, ncol), 1.66); w = np.array([1.0])
+    args = (sec, w, tau, lay, lev, e2, e2*20, None)
+    per_g = b.lw_solver_noscat(False, sec, w, tau, lay, lev, e2, e2*20, do_jacobians=True, sfc_src_jac=e2*0.3)
+    up = np.zeros((nlay+1, ncol)); dn = np.zeros((nlay+1, ncol)); dummy = np.zeros(1)
+    jac = np.full(2*(nlay+1)*ncol, -7.0)                       # the Jacobian and as much again of guard words
+    b.lib.call("rte_lw_solver_noscat", ncol, nlay, ngpt, BoolArg(False), 1, *args, dummy, dummy,
+               BoolArg(True), up, dn, BoolArg(True), e2*0.3, jac, BoolArg(False), tau, tau)
+    n = (nlay+1)*ncol
+    assert np.all(jac[n:] == -7.0), "written behind the (ncol, nlev) Jacobian"
+    assert cases.rel_err(jac[:n].reshape(nlay+1, ncol), per_g["flux_up_jac"].sum(axis=0)) <= 1e-12
+    assert cases.rel_err(up, per_g["flux_up"].sum(axis=0)) <= 1e-12
