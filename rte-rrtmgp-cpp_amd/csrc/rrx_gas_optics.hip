@@ -2394,8 +2394,11 @@ int gas_optics_lw_fractions_impl(
     const dim3 grid(ceil_div(ncol, 64), ceil_div(nlay, 4));
     const int ncmax = gas_window_ncmax(ngpt, nband);
     const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, 2, true);
-    // (the windowed kernel addresses a cell inside a g-point slab with a 32-bit byte offset)
-    const bool windowed = tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32);
+    // (the windowed kernel addresses a cell inside a g-point slab, and a node inside the kmajor / planck_frac tables, with 32-bit byte
+    //  offsets; a table beyond 4 GB -- far above any k-distribution -- goes to the gather kernels instead of wrapping. The minor and
+    //  Rayleigh tables are smaller than kmajor by the pressure dimension.)
+    const bool windowed = tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32)
+                          && size_t(ngpt)*ntemp*neta*(npres+1)*sizeof(F) < (size_t(1) << 32);
     StreamScratch scratch(st);
     const int geom = gas_window_geometry(ncol);
     const dim3 wgrid = gas_window_grid(geom, ncol, nlay);
@@ -2476,7 +2479,9 @@ int tau_absorption_impl(
         // windowed kernel first; the gather kernel then finishes the workgroups it handed back (usually none)
         const int ncmax = gas_window_ncmax(ngpt, nband);
         const size_t wlds = gas_window_lds_bytes<F>(ngpt, nmax, ncmax, MODE, false);
-        if (tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32))
+        // (32-bit byte offsets inside a g-point slab and inside the kmajor table, see gas_optics_lw_fractions_impl)
+        if (tuning().go_window && wlds <= 64*1024 && size_t(ncol)*nlay*sizeof(F) < (size_t(1) << 32)
+            && size_t(ngpt)*ntemp*neta*(npres+1)*sizeof(F) < (size_t(1) << 32))
         {
             hipStream_t st = static_cast<hipStream_t>(stream);
             StreamScratch scratch(st);

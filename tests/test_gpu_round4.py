@@ -249,3 +249,40 @@ def test_cpu_boundary_broadband_jacobian_is_sized_like_the_fluxes():
     assert np.all(jac[n:] == -7.0), "written behind the (ncol, nlev) Jacobian"
     assert cases.rel_err(jac[:n].reshape(nlay+1, ncol), per_g["flux_up_jac"].sum(axis=0)) <= 1e-12
     assert cases.rel_err(up, per_g["flux_up"].sum(axis=0)) <= 1e-12
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+@pytest.mark.parametrize("geom", ["0", "1"])
+def test_window_kernel_geometries_and_chunk_parts(kind, geom, hip_f64, oracle_f64, monkeypatch):
+    """The windowed gas optics in both workgroup shapes (RRX_GW_GEOM: 64 columns x 4 layers / 256 columns x 1 layer) on few columns --
+    the chunk loop is then shared out over grid.z, and with 8-g-point bands part 0 takes the whole range -- against the oracle, with
+    the census of the launch: the path that ran is asserted, not assumed."""
+    import os
+    monkeypatch.setenv("RRX_GW_GEOM", geom)
+    nbnd = 8
+    kd0 = synthetic.make_kdist(kind, ngpt=64, nbnd=nbnd, nminor_lower=2*nbnd, nminor_upper=nbnd)
+    atm0 = synthetic.make_atmosphere(320, 28, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=23)
+    res = []
+    for be in (hip_f64, oracle_f64):
+        kd = be.upload_kdist(kd0)
+        atm = pipeline.upload_atmosphere(be, atm0)
+        if be is hip_f64:
+            os.environ["RRX_GW_STATS"] = "1"
+            be.lib.cdll.rrx_gas_window_stats(None, None, 1)
+        try:
+            r = (pipeline.solve_lw if kind == "lw" else pipeline.solve_sw)(be, kd, atm, keep=True, do_broadband=True)
+        finally:
+            os.environ.pop("RRX_GW_STATS", None)
+        if be is hip_f64:
+            handed, total = ctypes.c_longlong(0), ctypes.c_longlong(0)
+            be.lib.cdll.rrx_gas_window_stats(ctypes.byref(handed), ctypes.byref(total), 1)
+            # geometry 1: 2 column blocks x 28 layers, geometry 0: 5 x 7 -- times the grid.z parts of a few-column launch
+            blocks = 2*28 if geom == "1" else 5*7
+            assert total.value > 0 and total.value % blocks == 0 and total.value // blocks in (1, 2, 4), (total.value, blocks)
+            # alike columns: at most the workgroups around the tropopause (geometry 0 only) are handed back
+            assert handed.value <= (0 if geom == "1" else total.value // 3), (handed.value, total.value)
+        res.append({k: be.to_numpy(v) for k, v in r.items() if v is not None and not isinstance(v, dict)})
+    h, o = res
+    for k in ("tau", "flux_up", "flux_dn", "flux_net"):
+        e = cases.rel_err(h[k], o[k])
+        assert e <= (1e-7 if (kind == "sw" and "flux" in k) else 1e-9), f"{kind} {k}: {e:.3e}"
