@@ -76,7 +76,8 @@ def _pmc_entry(stage, args):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path) or stage not in STAGE_KERNEL:
         return None
-    tag = f"{args.dtype}|{'broadband' if args.broadband else 'per-gpoint'}|{args.ncol}x{args.nlay}x{args.ngpt}|"
+    mode = ("broadband" if args.broadband else "per-gpoint") + ("-allsky" if getattr(args, "allsky", False) else "")
+    tag = f"{args.dtype}|{mode}|{args.ncol}x{args.nlay}x{args.ngpt}|"
     best = None
     for k, v in json.load(open(path)).items():
         if any(k.startswith(tag + kern) for kern in STAGE_KERNEL[stage]) and "fetch_bytes" in v and "write_bytes" in v:
