@@ -147,11 +147,12 @@ namespace rrx
     // exp(x) for finite x <= 0 (layer transmissivities exp(-tau*k), exp(-tau/mu0)): libm's exp without its overflow /
     // special-value handling. Range reduction x = n ln2 + r, |r| <= ln2/2 (ln2 split so that n*ln2_hi is exact), minimax
     // polynomial of degree 11 for exp(r) (fitted at Chebyshev nodes; approximation error 1.6e-17), 2^n through ldexp, which
-    // also delivers the underflow to 0 (x is clamped at -1000 so that n fits an int). Measured against glibc on 2e7
+    // also delivers the underflow to 0. Measured against glibc on 2e7
     // arguments in [-1e3, -1e-8]: at most 1.0 ulp. 19 instructions against about 27 for the library call.
-    __device__ __forceinline__ double exp_neg(double x)
+    __device__ __forceinline__ double exp_neg(const double x)
     {
-        x = fmax(x, -1000.0);
+        // (no clamp of x: n fits an int for x > -1.4e9, far beyond any finite optical depth x secant; round 3 clamped at -1000 with a
+        //  v_max_f64 per evaluation)
         const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
         double r = fma(n, -0x1.62e42f0000000p-1, x);
         r = fma(n, -0x1.df473de6af279p-26, r);

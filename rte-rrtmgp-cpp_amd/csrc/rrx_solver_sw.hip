@@ -43,6 +43,16 @@ constexpr int BB_EVALS = RRX_SW_BB_EVALS;   // fused broadband form: two_stream 
 #define RRX_SW_F32_WAVES 2    // waves per SIMD the fp32 geometry (16 x 4 lanes, one column per lane) is compiled for
 #endif
 
+#ifndef RRX_SW_TIMING
+#define RRX_SW_TIMING 0   // diagnostic build (tools/sw_timing.sh): wavefront 0 of every workgroup adds the clocks it spends per phase of a g-point to g_sw_clk
+#endif
+#if RRX_SW_TIMING
+__device__ unsigned long long g_sw_clk[16][8];      // [wavefront of the workgroup][phase]
+#define RRX_SW_T(k) { const unsigned long long t_ = __builtin_readcyclecounter(); sw_acc[k] += t_ - sw_t; sw_t = t_; }
+#else
+#define RRX_SW_T(k)
+#endif
+
 template<typename F>
 struct TwoStream { F r_dif, t_dif, r_dir, t_dir, t_noscat; };
 
@@ -205,8 +215,12 @@ sw_2stream_scan_kernel(
         n_inc = load_cols<F,V>(inc_flux_dir + s0); n_adir = load_cols<F,V>(sfc_alb_dir + s0); n_adif = load_cols<F,V>(sfc_alb_dif + s0);
     }
 
+#if RRX_SW_TIMING
+    unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_t = __builtin_readcyclecounter();
+#endif
     for (int igpt=g_begin; igpt<g_end; ++igpt)
     {
+    RRX_SW_T(7)
     // partner waves sharing 128-B lines issue their load bursts together (see rrx_solver_lw.hip); the pipelined form
     // issues them behind the first scan barrier instead
     if constexpr (!PRE) { if (sync_waves) __syncthreads(); }
@@ -288,6 +302,7 @@ sw_2stream_scan_kernel(
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    RRX_SW_T(0)
 
     // ---- (b) direct beam relative to the lane's incoming beam: prefix products of t_noscat, kept in LDS
     F Tloc[V];
@@ -340,7 +355,9 @@ sw_2stream_scan_kernel(
         if constexpr (W >= 2)
         {
             if (ll == LL-1) xch[8*v+0][wave][cl] = pr;
+            RRX_SW_T(1)
             __syncthreads();
+            RRX_SW_T(6)
             if constexpr (PRE)
             {
                 if (v == 0)
@@ -423,10 +440,12 @@ sw_2stream_scan_kernel(
             }
         }
         F x00 = F(1.), x01 = F(0.), x10 = F(0.);      // composite of everything below this wave's levels
+        RRX_SW_T(2)
         if constexpr (W == 2)
         {
             if (ll == 0) { xch[8*v+1][wave][cl] = m00; xch[8*v+2][wave][cl] = m01; xch[8*v+3][wave][cl] = m10; }
             __syncthreads();
+            RRX_SW_T(6)
             if (h == 0)
             {
                 x00 = xch[8*v+1][wave^1][cl]; x01 = xch[8*v+2][wave^1][cl]; x10 = xch[8*v+3][wave^1][cl];
@@ -440,6 +459,7 @@ sw_2stream_scan_kernel(
         {
             if (ll == 0) { xch[8*v+1][wave][cl] = m00; xch[8*v+2][wave][cl] = m01; xch[8*v+3][wave][cl] = m10; }
             __syncthreads();
+            RRX_SW_T(6)
             // composite of the waves below this one (the lowest applied first), then this wave's on top of it
             #pragma unroll
             for (int w=W-1; w>=1; --w)
@@ -492,10 +512,12 @@ sw_2stream_scan_kernel(
             if (ll + d < LL) { sbb = sa*b2 + sbb; sa = sa*a2; }
         }
         F xa = F(1.), xb = F(0.);
+        RRX_SW_T(3)
         if constexpr (W == 2)
         {
             if (ll == 0) { xch[8*v+4][wave][cl] = sa; xch[8*v+5][wave][cl] = sbb; }
             __syncthreads();
+            RRX_SW_T(6)
             if (h == 0)
             {
                 xa = xch[8*v+4][wave^1][cl]; xb = xch[8*v+5][wave^1][cl];
@@ -506,6 +528,7 @@ sw_2stream_scan_kernel(
         {
             if (ll == 0) { xch[8*v+4][wave][cl] = sa; xch[8*v+5][wave][cl] = sbb; }
             __syncthreads();
+            RRX_SW_T(6)
             #pragma unroll
             for (int w=W-1; w>=1; --w)
                 if (w > h) { const F oa = xch[8*v+4][w0+w][cl], ob = xch[8*v+5][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
@@ -538,10 +561,12 @@ sw_2stream_scan_kernel(
             if (ll >= d) { db = da*b2 + db; da = da*a2; }
         }
         xa = F(1.); xb = F(0.);
+        RRX_SW_T(4)
         if constexpr (W == 2)
         {
             if (ll == LL-1) { xch[8*v+6][wave][cl] = da; xch[8*v+7][wave][cl] = db; }
             __syncthreads();
+            RRX_SW_T(6)
             if (h == 1)
             {
                 xa = xch[8*v+6][wave^1][cl]; xb = xch[8*v+7][wave^1][cl];
@@ -552,6 +577,7 @@ sw_2stream_scan_kernel(
         {
             if (ll == LL-1) { xch[8*v+6][wave][cl] = da; xch[8*v+7][wave][cl] = db; }
             __syncthreads();
+            RRX_SW_T(6)
             #pragma unroll
             for (int w=0; w<W-1; ++w)
                 if (w < h) { const F oa = xch[8*v+6][w0+w][cl], ob = xch[8*v+7][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
@@ -600,7 +626,11 @@ sw_2stream_scan_kernel(
             store_cols<F,V>(flux_dir + o, odr);
         }
     }
+    RRX_SW_T(5)
     }   // g-point loop
+#if RRX_SW_TIMING
+    if (lane == 0) for (int k=0; k<8; ++k) atomicAdd(&g_sw_clk[wave & 15][k], sw_acc[k]);
+#endif
 
     if constexpr (BB)
     {
@@ -931,6 +961,16 @@ int apply_BC_impl(int ncol, int nlay, int ngpt, Bool top_at_1, const F* inc, con
 extern "C"
 {
 int rrx_set_sw_variant(int v) { rrx::tuning().sw_variant = v; return 0; }
+#if RRX_SW_TIMING
+// diagnostic build only: phase clocks per wavefront of a workgroup (out[16][8]) summed over the workgroups since the last call (two-stream, direct beam, albedo, source, down scan,
+// final replay, barrier waits, loop top), then reset
+int rrx_sw_timing(unsigned long long* out)
+{
+    unsigned long long zero[16*8] = {0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sw_clk), 16*8*sizeof(unsigned long long)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sw_clk), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
 int rrx_set_broadband_min_groups(int n) { rrx::tuning().bb_min_groups = n; return 0; }
 int rrx_set_broadband_gsplit(int n) { rrx::tuning().bb_gsplit = n; return 0; }
 
