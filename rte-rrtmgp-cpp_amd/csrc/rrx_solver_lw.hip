@@ -345,6 +345,15 @@ lw_noscat_scan_kernel(
 #ifndef RRX_LW_LACC
 #define RRX_LW_LACC 1
 #endif
+#ifndef RRX_LW_TIMING
+#define RRX_LW_TIMING 0   // diagnostic build (tools/sw_timing.sh): every wavefront adds the clocks it spends per phase of a g-point to g_lw_clk
+#endif
+#if RRX_LW_TIMING
+__device__ unsigned long long g_lw_clk[16][8];
+#define RRX_LW_T(k) { const unsigned long long t_ = __builtin_readcyclecounter(); lw_acc[k] += t_ - lw_t; lw_t = t_; }
+#else
+#define RRX_LW_T(k)
+#endif
 #ifndef RRX_LW_LACC32
 #define RRX_LW_LACC32 1    // fp32, two columns per lane: g-point sums in LDS columns too (round 4: the register form spilled 37-41 VGPRs)
 #endif
@@ -444,8 +453,12 @@ lw_noscat_bb_kernel(
     const F wgt = weights[0];
     const F scale = pi * wgt;
 
+#if RRX_LW_TIMING
+    unsigned long long lw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lw_t = __builtin_readcyclecounter();
+#endif
     for (int igpt=g_lo; igpt<g_hi; ++igpt)
     {
+    RRX_LW_T(7)
     if constexpr (!PRE) __syncthreads();        // partner waves issue their load bursts together
     Loads cur;
     if constexpr (PRE) cur = nxt; else issue(igpt, cur);
@@ -481,15 +494,13 @@ lw_noscat_bb_kernel(
         if constexpr (!LITE) return (j < K) ? cur.a2[min(j, K-1)].v[v] : cur.x_next.v[v];
         else
         {
-            const int t = t0 + j;
             const F pa = (j == 0) ? cur.x_prev.v[v] : cur.a1[max(j-1, 0)].v[v];
             const F pb = (j == K) ? cur.x_next.v[v] : cur.a1[min(j, K-1)].v[v];
             const F bvv = lds_b[(K+j)*V+v][tid];
-            // selects, not branches: the first and the last level take the fraction of their one layer (every lane evaluates the
-            // square root anyway; two divergent branches per level cost more scalar instructions than the selects)
-            const F mid = sqrt_pos(pa*pb);
-            const F f = (t <= 0) ? pb : ((t >= nlay) ? pa : mid);
-            return f * bvv;
+            // The first and the last level take the fraction of their one layer (gas_optics_rrtmgp_kernels.cu:260-306). No select for
+            // that (round 4; rounds 2-3 spent four v_cndmask per level on it): the loads of the neighbouring layer are clamped into the
+            // column (lay_off), so there pa == pb and sqrt_pos(p*p) returns p -- the residual of its last Newton step is exact.
+            return sqrt_pos(pa*pb) * bvv;
         }
     };
 
@@ -525,6 +536,7 @@ lw_noscat_bb_kernel(
         }
     }
 
+    RRX_LW_T(0)
     F dn_in[V], up_in[V];
     #pragma unroll
     for (int v=0; v<V; ++v)
@@ -539,7 +551,9 @@ lw_noscat_bb_kernel(
         }
         F xa = F(1.), xb = F(0.);
         if (ll == LL-1) { xch[4*v+0][wave][cl] = a; xch[4*v+1][wave][cl] = b; }
+        RRX_LW_T(1)
         __syncthreads();
+        RRX_LW_T(6)
         if constexpr (PRE)
         {
             if (v == 0)
@@ -576,7 +590,9 @@ lw_noscat_bb_kernel(
         }
         xa = F(1.); xb = F(0.);
         if (ll == 0) { xch[4*v+2][wave][cl] = a; xch[4*v+3][wave][cl] = b; }
+        RRX_LW_T(2)
         __syncthreads();
+        RRX_LW_T(6)
         #pragma unroll
         for (int w=W-1; w>=1; --w)
             if (w > h) { const F oa = xch[4*v+2][w0+w][cl], ob = xch[4*v+3][w0+w][cl]; xb = oa*xb + ob; xa = oa*xa; }
@@ -606,7 +622,11 @@ lw_noscat_bb_kernel(
             else add_rounded(acc_up[j][v], scale*up);
         }
     }
+    RRX_LW_T(3)
     }   // g-point loop
+#if RRX_LW_TIMING
+    if (lane == 0) for (int k=0; k<8; ++k) atomicAdd(&g_lw_clk[wave & 15][k], lw_acc[k]);
+#endif
 
     if (!writer) return;
     #pragma unroll
@@ -1127,6 +1147,16 @@ int lw_solver_noscat_fractions_impl(
 extern "C"
 {
 int rrx_set_lw_variant(int v) { rrx::tuning().lw_variant = v; return 0; }
+#if RRX_LW_TIMING
+// diagnostic build only: phase clocks per wavefront of a workgroup (out[16][8]: sources + transmissivities, down scan, up scan, replays + sums,
+// -, -, barrier waits, loop top) summed over the workgroups since the last call, then reset
+int rrx_lw_timing(unsigned long long* out)
+{
+    unsigned long long zero[16*8] = {0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lw_clk), 16*8*sizeof(unsigned long long)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lw_clk), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int rrx_lw_secants_array_f64(int ncol, int ngpt, int n_gauss_quad, int max_gauss_pts, const double* gauss_Ds, double* secants, void* stream)
 {
