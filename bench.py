@@ -155,6 +155,32 @@ def cpu_baseline(args, kd_lw0, kd_sw0, be=None):
     return out
 
 
+def fp32_against_fp64(args, nbnd, rank, world, solver32, kd_lw0, kd_sw0, ncheck=256):
+    """--dtype f32: the first columns of this rank solved once more in fp64 by the same HIP path, and the largest difference of the
+    fp32 broadband fluxes from them in W m-2 -- the unit of the reference's own acceptance gate (5.8e-2 W m-2 against its reference
+    fluxes, .github/workflows/continuous-integration.yml:58-62). Outside the timed region."""
+    import rte_rrtmgp_cpp_amd as R
+    from rte_rrtmgp_cpp_amd import synthetic, pipeline, sharding
+    ntot = global_columns(args, world)
+    s, e = sharding.column_range(rank, world, ntot)
+    n = min(ncheck, e - s)
+    atm0 = synthetic.make_atmosphere(ntot, args.nlay, nbnd_lw=nbnd, nbnd_sw=nbnd, seed=1234, col_range=(s, s + n),
+                                     top_at_1=getattr(args, "top_at_1", False), clouds=getattr(args, "allsky", False))
+    if getattr(args, "col_spread", 0.0) > 0:
+        atm0 = spread_columns(atm0, args.col_spread, s, s + n, ntot)
+    be64 = R.HipKernels(np.float64, solver32.be.device)
+    luts = None
+    if args.allsky:
+        luts = (be64.upload_lut(synthetic.make_cloud_lut(nbnd, "lw")), be64.upload_lut(synthetic.make_cloud_lut(nbnd, "sw")))
+    ref = pipeline.ResidentSolver(be64, be64.upload_kdist(kd_lw0), be64.upload_kdist(kd_sw0), pipeline.upload_atmosphere(be64, atm0),
+                                  do_broadband=args.broadband, cloud_luts=luts, sort_columns="0").step()
+    got = solver32.fluxes[:, :, :n].double()
+    d = (got - ref).abs().amax(dim=(1, 2)).tolist()
+    names = ("lw_flux_up", "lw_flux_dn", "lw_flux_net", "sw_flux_up", "sw_flux_dn", "sw_flux_dn_dir", "sw_flux_net")
+    return {"columns": n, "unit": "W m-2", "max_abs_difference": {k: round(v, 5) for k, v in zip(names, d)},
+            "reference_gate": 5.8e-2}
+
+
 def launch_command(argv, gpus, port=None):
     """What `bench.py --gpus N` (N > 1) runs when it was not started by torch.distributed.run: the documented launcher
     as a CHILD process, one rank per GPU. Nothing in this process has touched the GPU (or imported torch) at that point."""
@@ -438,6 +464,8 @@ def main():
                 out["roofline_valu"]["stale"] = bool(stale)
         if handed is not None:
             out["gas_window"] = handed
+        if args.dtype == "f32" and args.driver == "python":
+            out["fp32_vs_fp64"] = fp32_against_fp64(args, nbnd, rank, world, solver, kd_lw0, kd_sw0)
         if other is not None:
             out["other_scaling"] = other
         if world > 1:       # what a SCALE record can be checked against

@@ -135,7 +135,8 @@ def test_tall_columns_fp32_broadband_mode(kind, hip_f32, oracle_f32):
     for ncol, nlay in ((24, 230), (12, 400)):
         h, o = _solve_both(hip_f32, oracle_f32, kind, ncol, nlay, False, False, do_broadband=True)
         for k in ("flux_up", "flux_dn", "flux_net"):
-            assert cases.rel_err(h[k], o[k], floor=1e-2) <= (1e-3 if kind == "sw" else 2e-4), (k, nlay)     # (fp32 two-stream scans: as test_c5_fp32_…)
+            # (round 4: twice what is observed -- SW 3.1e-4, LW 1.4e-5; the bounds of rounds 2-3 were 1e-3 / 2e-4)
+            assert cases.rel_err(h[k], o[k], floor=1e-2) <= (6e-4 if kind == "sw" else 3e-5), (k, nlay)
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
@@ -145,7 +146,7 @@ def test_full_solve_fp32_matches_fp32_oracle(kind, hip_f32, oracle_f32):
     gas_optics_rrtmgp_kernels.cu:377-379), so fp32 and fp64 runs of the SAME code differ by percents in tau."""
     h, o = _solve_both(hip_f32, oracle_f32, kind, 64, 60, False, False)
     for k in ("flux_up", "flux_dn", "flux_net", "tau"):
-        assert cases.rel_err(h[k], o[k], floor=1e-2) <= 2e-4, k
+        assert cases.rel_err(h[k], o[k], floor=1e-2) <= (1.5e-4 if kind == "sw" else 1e-5), k      # (observed 7.3e-5 / 3.9e-6)
 
 
 @pytest.mark.parametrize("kind", ["lw", "sw"])
@@ -639,7 +640,7 @@ def test_c5_fp32_allsky_matches_fp32_oracle(kind, hip_f32, oracle_f32, oracle_f6
     worst = _worst(h, o, keys, floor=1e-2)
     print(f"C5 fp32 all-sky {kind}: worst rel err", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     for k, e in worst.items():
-        assert e <= (1e-3 if (kind == "sw" and "flux" in k) else 2e-4), f"{kind} {k}: {e:.3e}"
+        assert e <= (3e-4 if kind == "sw" else 1e-4), f"{kind} {k}: {e:.3e}"        # (round 4: twice what is observed, 1.3e-4 / 2.9e-5; before 1e-3 / 2e-4)
     # broadband fluxes with a floor of 1e-4 instead of 1e-2: the sums over 256 g-points are well conditioned
     flux_keys = ("flux_up", "flux_dn", "flux_net") + (("flux_dn_dir",) if kind == "sw" else ())
     tight = _worst(h, o, flux_keys, floor=1e-4)

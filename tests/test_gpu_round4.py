@@ -28,8 +28,7 @@ def _random_columns(rng, ngpt, nlay, ncol):
 def test_fp32_broadband_solvers_one_column_per_lane(ncol, nlay, top_at_1, with_g, hip_f32, oracle_f32):
     """fp32 do_broadband: the 16 x 4-lane geometry (SW default; LW for odd column counts and under variant 15) against the fp32
     oracle, on odd and even column counts, every K of the tiling (20 ... 190 layers), with g (all-sky form, pipelined loads of tau,
-    ssa AND g) and without (clear-sky form). Bounds as for the other fp32 solver tests (random optical properties sit on the
-    two-stream clamps: 1e-3 there)."""
+    ssa AND g) and without (clear-sky form). Bounds: twice the worst error observed."""
     rng = np.random.default_rng(100*nlay + ncol)
     ngpt = 6
     tau, ssa, g, lay, lev, e2, mu0 = _random_columns(rng, ngpt, nlay, ncol)
@@ -50,7 +49,7 @@ def test_fp32_broadband_solvers_one_column_per_lane(ncol, nlay, top_at_1, with_g
         out.append([be.to_numpy(x) for x in (l["flux_up"], l["flux_dn"], s["flux_up"], s["flux_dn"], s["flux_dir"])])
     for name, a15, a0, o in zip(("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dir"), *out):
         assert a0.shape == o.shape == (nlay+1, ncol)
-        tol = 2e-5 if name.startswith("lw") else 1e-3
+        tol = 5e-5 if name.startswith("lw") else 2e-4           # (twice what is observed: 9e-5 in SW)
         assert cases.rel_err(a0, o, floor=1e-2) <= tol, name
         assert cases.rel_err(a15, o, floor=1e-2) <= tol, name + " (one column per lane)"
 
@@ -70,7 +69,7 @@ def test_fp32_sw_geometries_agree(hip_f32):
             be.set_variant(sw=0)
         res.append([be.to_numpy(s[k]) for k in ("flux_up", "flux_dn", "flux_dir")])
     for a, b in zip(*res):
-        assert cases.rel_err(a, b, floor=1e-2) <= 1e-3
+        assert cases.rel_err(a, b, floor=1e-2) <= 5e-6          # (observed 6e-7)
 
 
 def test_window_tables_follow_the_contents_not_the_pointers(hip_f64, oracle_f64):
