@@ -1289,11 +1289,15 @@ constexpr int NCW = 6;                       // minor contributors of a chunk wi
 constexpr int NXW = 12;                      // ... and how many a chunk may have at all: those beyond NCW are added in a pass of their own behind the g-point loop
 
 // Parts (grid.z) the chunk loop of the windowed kernel is shared out over: 1 when the (column, layer) workgroups alone fill the
-// chip a few times over (three resident per CU), else 2 or 4
+// chip once (three resident per CU), else 2 or 4
 inline int gas_window_parts(const int nblk, const int nchunk)
 {
+    static const int forced = std::getenv("RRX_GW_PARTS") ? std::atoi(std::getenv("RRX_GW_PARTS")) : 0;      // (A/B runs)
+    if (forced > 0) return std::min(forced, nchunk);
+    // (round 4, RRX_GW_PARTS sweep at 2 048 and 4 096 columns: a split pays only while the workgroups do not fill the 768 resident
+    //  places once -- every part repeats the set-up of its workgroup, a tenth of its life; 1 120 workgroups: 0.43 ms in one part or two)
     int nz = 1;
-    while (nblk*nz < 2048 && nz < 4 && 2*nz <= nchunk) nz *= 2;
+    while (nblk*nz < 768 && nz < 4 && 2*nz <= nchunk) nz *= 2;
     return nz;
 }
 
