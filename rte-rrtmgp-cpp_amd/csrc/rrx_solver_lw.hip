@@ -334,7 +334,7 @@ lw_noscat_scan_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused broadband form, second generation (round 2). Same tiling and scans as lw_noscat_scan_kernel<..., BB = true>, plus
 //   PRE  : software pipeline over the g-point loop -- the loads of g-point g+1 are requested behind the first scan barrier
-//          of g-point g and land during its scans and replays (tools/lw_lab.hip: 2.78 -> 2.59 ms at C4 fp64);
+//          of g-point g and land during its scans and replays (tools/labs/lw_lab.hip: 2.78 -> 2.59 ms at C4 fp64);
 //   LITE : "Planck-lite" inputs. Instead of lay_source and lev_source the kernel reads the Planck fractions pfrac(col,lay,gpt)
 //          and the band-integrated Planck functions B_lay(col,lay,bnd), B_lev(col,lev,bnd), and rebuilds
 //          lay_source = pfrac*B_lay, lev_source = sqrt(pfrac*pfrac')*B_lev (first and last level: pfrac*B_lev) itself,

@@ -120,7 +120,7 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // fluxes, so the same bits; flux_up/dn/dir are then (ncol, nlev) arrays.
 // PRE (BB form without g array): software pipeline over the g-point loop. The K layers of tau and ssa of g-point g+1 are
 // requested right after the two-stream phase of g-point g, when the registers of its temporaries are free, and land
-// during the scans and replays; the next iteration finds them in registers. Measured at C4 (tools/sw_lab.hip): 5.3 -> 4.7 ms;
+// during the scans and replays; the next iteration finds them in registers. Measured at C4 (tools/labs/sw_lab.hip): 5.3 -> 4.7 ms;
 // loads issued layer by layer inside the two-stream phase were still in flight when their layer came up.
 // W = 4 (round 3): four wavefronts per column group, eight per workgroup (two column groups, as with W = 2): columns of up to 287
 // layers at nine layers per lane; the wave totals of a scan are then combined over the group's waves in order (the W = 2 code is
