@@ -7,6 +7,7 @@
 #include <memory>
 #include <string>
 #include "Radiation_solver.h"
+#include "rrx_cxx_driver.h"
 
 namespace
 {

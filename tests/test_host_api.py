@@ -57,6 +57,25 @@ def test_host_library_exports_driver_entry():
     assert os.path.exists(os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", "test_rte_rrtmgp_gpu"))
 
 
+def test_host_libraries_export_the_cxx_driver_api():
+    """Every symbol include_test/rrx_cxx_driver.h declares is exported by both precisions of the host library (what
+    bench.py --driver cxx and a foreign host model bind), and creating a driver without a GPU fails with a message, not a crash."""
+    import re
+    hdr = open(os.path.join(ROOT, "include_test", "rrx_cxx_driver.h")).read()
+    names = sorted(set(re.findall(r"\b(rrx_cxx_driver_\w+)\s*\(", hdr)))
+    assert len(names) == 7, names
+    for sfx in ("", "_sp"):
+        lib = ctypes.CDLL(os.path.join(ROOT, "rte-rrtmgp-cpp_amd", "lib", f"librte_rrtmgp_hip{sfx}.so"))
+        for n in names:
+            assert hasattr(lib, n), (sfx, n)
+    import torch
+    if not torch.cuda.is_available():
+        lib.rrx_cxx_driver_create.restype = ctypes.c_void_p
+        lib.rrx_cxx_driver_error.restype = ctypes.c_char_p
+        h = lib.rrx_cxx_driver_create(b"/nonexistent", 0, None, 0, 0)
+        assert not h and len(lib.rrx_cxx_driver_error()) > 0
+
+
 def test_rrxb_roundtrip(tmp_path):
     import numpy as np
     from rte_rrtmgp_cpp_amd import rrxio
