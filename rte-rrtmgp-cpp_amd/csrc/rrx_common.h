@@ -163,6 +163,42 @@ namespace rrx
         const double t = fma(r*r, p, r);
         return __builtin_amdgcn_ldexp(t + 1.0, (int)n);
     }
+    // The same function through a 64-entry table of 2^(j/64) in LDS (the fused broadband solvers, whose bound is fp64 issue):
+    // x = (64 e + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^e * T[j] * (1 + r + r^2 p(r)) with a degree-3 p (truncation 3.5e-17). The
+    // integer 64 e + j is read from the low word of x*64/ln2 + 1.5*2^52 (no conversion instruction); e comes from a saturating
+    // conversion so that an absurd argument still ends in ldexp(.., INT_MIN) = 0. 15 vector instructions + one ds_read against 19;
+    // at most 1.3 ulp from glibc on 2e7 arguments in [-1e3, -1e-8] (host model of the same arithmetic).
+    static __device__ const double exp2_64_table[64] = {
+        0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0, 0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0,
+        0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0, 0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+        0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0, 0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0,
+        0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0, 0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+        0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0, 0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0,
+        0x1.6247eb03a5585p+0, 0x1.6623882552225p+0, 0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+        0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0, 0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0,
+        0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0, 0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+        0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0, 0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0,
+        0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0, 0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+        0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+    __device__ __forceinline__ void exp_table_fill(double* lds_table)      // (the caller places a barrier before the first use)
+    {
+        if (threadIdx.x < 64) lds_table[threadIdx.x] = exp2_64_table[threadIdx.x];
+    }
+    __device__ __forceinline__ double exp_neg(const double x, const double* lds_table)
+    {
+        const double magic = 0x1.8p+52;
+        const double t = fma(x, 0x1.71547652b82fep+6, magic);
+        const double nf = t - magic;
+        double r = fma(nf, -0x1.62e42fefa0000p-7, x);
+        r = fma(nf, -0x1.cf79abc9e3b3ap-46, r);
+        const int j = __double2loint(t) & 63;
+        const int e = ((int)nf >> 6);
+        const double T = lds_table[j];
+        double p = 0x1.1111111111111p-7;
+        p = fma(p, r, 0x1.5555555555555p-5); p = fma(p, r, 0x1.5555555555555p-3); p = fma(p, r, 0.5);
+        const double q = fma(r*r, p, r);
+        return __builtin_amdgcn_ldexp(fma(T, q, T), e);
+    }
     // fp32: v_exp_f32 (2^p, 1 ulp) on p = x log2(e), with the rounding error of that product and the tail of log2(e) added back
     // to first order (exp2(p + d) = exp2(p)(1 + d ln 2)): 5 VALU + 1 transcendental instruction against the library's ~14
     // (its range handling: x <= 0 needs none; results below FLT_MIN flush to zero).
@@ -173,6 +209,7 @@ namespace rrx
         const float y = __builtin_amdgcn_exp2f(p);
         return fmaf(y, d * 0x1.62e430p-1f, y);
     }
+    __device__ __forceinline__ float exp_neg(const float x, const float*) { return exp_neg(x); }
 
     // sqrt(x) for normal x well inside the exponent range (here: k^2 in [1e-12, 16]): v_rsq_f64 (2^-23) + one coupled
     // Goldschmidt step + one Newton correction, i.e. the library sequence without its scaling of tiny arguments and its

@@ -24,6 +24,21 @@ namespace
 #ifndef RRX_GW_ABL
 #define RRX_GW_ABL 0      // ablation builds (tools/ab_extra.sh, tools/gw_timing.sh): 1 = set-up only, 2 = no staging, 3 = no g-point loop, 7 = no stores
 #endif
+// The same store addressed as uniform 64-bit base + 32-bit unsigned lane offset: the instruction's own scalar-base form, written as
+// such (through C++ the compiler folds base and offset back into a 64-bit address per lane, one v_lshl_add_u64 per store). Counted by
+// the hardware's vmcnt like any store; the compiler does not know of it, which only makes its own waits conservative.
+template<typename F> __device__ __forceinline__ void stream_store_sbase(const char* sbase, const unsigned voff, const F v)
+{
+    static_assert(sizeof(F) == 4 || sizeof(F) == 8, "dword or dwordx2");
+    if (RRX_GW_ABL == 7) { if (v == F(-12345.678)) *reinterpret_cast<F*>(const_cast<char*>(sbase) + voff) = v; return; }
+#if RRX_GW_NT
+    if constexpr (sizeof(F) == 4) asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+#else
+    if constexpr (sizeof(F) == 4) asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+#endif
+}
 template<typename F> __device__ __forceinline__ void stream_store(F* p, const F v)
 {
     if (RRX_GW_ABL == 7) { if (v == F(-12345.678)) *p = v; return; }
@@ -2101,6 +2116,7 @@ gas_window_kernel(
         const int m00 = (pi0*NEW + e0)*NTW + ti, m10 = (pi0*NEW + e1)*NTW + ti;      // kmajor: pressure node jp-1, eta node je-1
         const int q0 = e0*NTW + ti, q1 = e1*NTW + ti;                               // kminor / krayl
         const bool wave_same_eta = !__any(je[0] != je[1]);
+        const bool wave_all_active = !__any(!active);
 
         // band Planck functions and surface terms of the fractions form, once per band. The band is looked up once per chunk where the
         // chunk lies in one band (the rule): a per-g-point look-up is a global load the wavefront waits for with `vmcnt(0)`, i.e.
@@ -2140,10 +2156,37 @@ gas_window_kernel(
         // (a single chain leaves the SIMD idle for most of each LDS round trip with three waves to cover it). The paired form
         // is taken when every contributor of the chunk spans the whole chunk (the rule: intervals are band-aligned), so it
         // needs no per-g-point range tests.
-        auto gstep = [&](auto U_, auto CHK_, const int gi0)
+        // bit gi of cmask[i]: contributor i is present at g-point c0 + gi (its interval [slo, shi) cut to the chunk; 0 beyond the list)
+        unsigned cmask[NCW];
+        #pragma unroll
+        for (int i=0; i<NCW; ++i)
+        {
+            const int lo = max(slo[i] - c0, 0), hi = min(shi[i] - c0, ng);
+            cmask[i] = (i < n && hi > lo) ? (((hi >= 32) ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+        }
+        // Scalar instructions are not free (tools/issue_mix_bench.hip: a wavefront's s_* instruction costs its SIMD 2.8-4 cycles of issue,
+        // as much as a vector one; the loop executed ~45 of them per g-point next to ~50 vector ones). Hence: (i) whether the wavefront's
+        // cells share one eta index is decided once per chunk, not at every read (SAME_: two copies of the loop); (ii) "is contributor i
+        // present at this g-point" is one bit test on a per-chunk mask instead of two compares against the interval's limits.
+        // (iii) the stores address their g-point slab through a uniform 64-bit pointer that walks along with the loop (two scalar adds
+        // per array and g-point; the compiler's own form re-multiplied ig * ncol * nlay and added it to a 64-bit address per lane: nine
+        // scalar and two 64-bit vector instructions); (iv) a wavefront whose lanes all own a cell (ACT_: every wavefront but those of
+        // the last column block) runs a copy of the loop without the store predicate.
+        const size_t slab_b = ncl*SZ;
+        char* sb_tau = reinterpret_cast<char*>(tau) + size_t(c0)*slab_b;
+        [[maybe_unused]] char* sb_ssa = (MODE != 2) ? reinterpret_cast<char*>(ssa) + size_t(c0)*slab_b : nullptr;
+        [[maybe_unused]] char* sb_g = (MODE != 2 && CLD) ? reinterpret_cast<char*>(g) + size_t(c0)*slab_b : nullptr;
+        [[maybe_unused]] char* sb_pf = nullptr;
+        if constexpr (PF) sb_pf = reinterpret_cast<char*>(pa.pfrac) + size_t(c0)*slab_b;
+        auto slab_put = [&](char* sbase, const int u, const F v)
+        {
+            stream_store_sbase<F>(sbase + size_t(u)*slab_b, idx_b, v);
+        };
+        auto gstep = [&](auto U_, auto SAME_, auto ACT_, const int gi0)
         {
             constexpr int U = decltype(U_)::value;
-            constexpr bool CHK = decltype(CHK_)::value;
+            constexpr bool SAME = decltype(SAME_)::value;
+            constexpr bool ACT = decltype(ACT_)::value;
             Vec2 a0[U], a1[U], a2[U], a3[U]; F k4[U], k5[U], k6[U], k7[U], t[U];
             #pragma unroll
             for (int u=0; u<U; ++u)
@@ -2153,7 +2196,7 @@ gas_window_kernel(
                 a0[u] = wm[m00]; a1[u] = wm[m00 + NTW]; a2[u] = wm[m00 + NEW*NTW]; a3[u] = wm[m00 + NEW*NTW + NTW];
                 k4[u] = a0[u].y; k5[u] = a1[u].y; k6[u] = a2[u].y; k7[u] = a3[u].y;
             }
-            if (!wave_same_eta)
+            if constexpr (!SAME)
             {
                 #pragma unroll
                 for (int u=0; u<U; ++u)
@@ -2169,7 +2212,7 @@ gas_window_kernel(
             #pragma unroll
             for (int i=0; i<NCW; ++i)                                   // ascending contributor index: the reference's order
             {
-                if (i < n && (!CHK || (c0 + gi0 >= slo[i] && c0 + gi0 < shi[i])))
+                if ((cmask[i] >> gi0) & 1u)
                 {
                     Vec2 c0v[U], c1v[U]; F m2[U], m3[U];
                     #pragma unroll
@@ -2178,7 +2221,7 @@ gas_window_kernel(
                         const Vec2* wn = Wmin + (i*GCH + gi0 + u)*MBOX;
                         c0v[u] = wn[q0]; c1v[u] = wn[q0 + NTW]; m2[u] = c0v[u].y; m3[u] = c1v[u].y;
                     }
-                    if (!wave_same_eta)
+                    if constexpr (!SAME)
                     {
                         #pragma unroll
                         for (int u=0; u<U; ++u) { const Vec2* wn = Wmin + (i*GCH + gi0 + u)*MBOX; m2[u] = wn[q1].y; m3[u] = wn[q1 + NTW].y; }
@@ -2197,7 +2240,7 @@ gas_window_kernel(
                 Vec2 r0[U], r1[U]; F r2[U], r3[U];
                 #pragma unroll
                 for (int u=0; u<U; ++u) { const Vec2* wr = Wray + (gi0 + u)*MBOX; r0[u] = wr[q0]; r1[u] = wr[q0 + NTW]; r2[u] = r0[u].y; r3[u] = r1[u].y; }
-                if (!wave_same_eta)
+                if constexpr (!SAME)
                 {
                     #pragma unroll
                     for (int u=0; u<U; ++u) { const Vec2* wr = Wray + (gi0 + u)*MBOX; r2[u] = wr[q1].y; r3[u] = wr[q1 + NTW].y; }
@@ -2219,8 +2262,8 @@ gas_window_kernel(
                 }
                 if constexpr (MODE == 2)
                 {
-                    if constexpr (CLD) { if (active) slab_store(tau, ig, t[u] + c_tau); }
-                    else if (active) slab_store(tau, ig, t[u]);
+                    if constexpr (CLD) { if (ACT || active) slab_put(sb_tau, u, t[u] + c_tau); }
+                    else if (ACT || active) slab_put(sb_tau, u, t[u]);
                 }
                 else
                 {
@@ -2230,13 +2273,12 @@ gas_window_kernel(
                     {
                         F gg = F(0.);
                         add_by_band_2str<F, RRX_GW_FAST_BYBAND != 0>(tt, ww, gg, c_tau, c_ssa, c_g);
-                        if (active) { slab_store(tau, ig, tt); slab_store(ssa, ig, ww); slab_store(g, ig, gg); }
+                        if (ACT || active) { slab_put(sb_tau, u, tt); slab_put(sb_ssa, u, ww); slab_put(sb_g, u, gg); }
                     }
-                    else if (active)
+                    else if (ACT || active)
                     {
-                        slab_store(tau, ig, tt);
-                        slab_store(ssa, ig, ww);
-                        if (g != nullptr) slab_store(g, ig, F(0.));
+                        slab_put(sb_tau, u, tt);
+                        slab_put(sb_ssa, u, ww);                // (a g array of a cloudless launch is zeroed behind the loop)
                     }
                 }
                 if constexpr (PF)
@@ -2244,16 +2286,16 @@ gas_window_kernel(
                     const Vec2* wp = Wpf + gi*WBOX;
                     const Vec2 p0 = wp[m00], p1 = wp[m00 + NTW], p2 = wp[m00 + NEW*NTW], p3 = wp[m00 + NEW*NTW + NTW];
                     F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
-                    if (!wave_same_eta) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
+                    if constexpr (!SAME) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
                     const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
                     if (!one_band)                                  // (a chunk with a band boundary inside: not the rule)
                     {
                         const int ibnd = rfl(pa.gpoint_bands[ig]) - 1;
                         if (ibnd != cur_bnd) band_update(ibnd);
                     }
-                    if (active)
+                    if (ACT || active)
                     {
-                        slab_store(pa.pfrac, ig, pfrac);
+                        slab_put(sb_pf, u, pfrac);
                         if (is_sfc)
                         {
                             pa.sfc_src    [icol + size_t(ig)*ncol] = pfrac * b_sfc;
@@ -2262,12 +2304,19 @@ gas_window_kernel(
                     }
                 }
             }
+            sb_tau += U*slab_b;
+            if constexpr (MODE != 2) sb_ssa += U*slab_b;
+            if constexpr (MODE != 2 && CLD) sb_g += U*slab_b;
+            if constexpr (PF) sb_pf += U*slab_b;
         };
 
         // every contributor of the chunk spans the chunk: no range tests, g-points can go in pairs
         bool chunk_full = true;
         #pragma unroll
         for (int i=0; i<NCW; ++i) if (i < n && !(slo[i] <= c0 && shi[i] >= gend)) chunk_full = false;
+#ifndef RRX_GW_PAIR32
+#define RRX_GW_PAIR32 1    // fp32 pairs the g-points of the fractions form only (LW stage 1.78 -> 1.69 ms at C4; SW 1.38 -> 1.49 paired)
+#endif
 #ifndef RRX_GW_PAIR_PF
 #define RRX_GW_PAIR_PF 1
 #endif
@@ -2276,15 +2325,34 @@ gas_window_kernel(
 #endif
         // (the fractions form and the all-sky SW form have no registers to spare in fp64: paired they spill, and a spill reload waits
         //  behind every store in flight)
-        // (fp32: unpaired is faster in every form -- LW stage 2.05 -> 1.87 ms, SW 1.56 -> 1.50 ms at C4, tools/ab_extra.sh)
+        // (fp32: unpaired was faster in every form while the loop still carried its range tests -- LW stage 2.05 -> 1.87 ms, SW 1.56 -> 1.50 ms
+        //  at C4; with the bit masks the fractions form gains from pairs, RRX_GW_PAIR32 above, the SW forms still do not)
         // (fractions form, fp64: paired it spills 72 B per lane and is still 3 % faster now that nothing in its loop waits on `vmcnt` --
         //  2.76 -> 2.68 ms, two boxes; before the band look-up left the loop it was 3 % slower. Not in the all-sky form.)
-        constexpr int PAIR = (RRX_GW_PAIR && sizeof(F) == 8 && ((RRX_GW_PAIR_PF && !CLD) || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
-        if (RRX_GW_ABL != 3)
-        for (int gi=0; gi<ng; )
+        constexpr int PAIR = (RRX_GW_PAIR && (sizeof(F) == 8 || (RRX_GW_PAIR32 && PF)) && ((RRX_GW_PAIR_PF && !CLD) || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
+        auto gloop = [&](auto SAME_, auto ACT_)
         {
-            if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, std::false_type{}, gi); gi += 2; }
-            else { gstep(std::integral_constant<int,1>{}, std::true_type{}, gi); gi += 1; }
+            for (int gi=0; gi<ng; )
+            {
+                if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, SAME_, ACT_, gi); gi += 2; }
+                else { gstep(std::integral_constant<int,1>{}, SAME_, ACT_, gi); gi += 1; }
+            }
+        };
+        if (RRX_GW_ABL != 3)
+        {
+            if (wave_all_active)
+            {
+                if (wave_same_eta) gloop(std::true_type{}, std::true_type{}); else gloop(std::false_type{}, std::true_type{});
+            }
+            else
+            {
+                if (wave_same_eta) gloop(std::true_type{}, std::false_type{}); else gloop(std::false_type{}, std::false_type{});
+            }
+            if constexpr (MODE != 2 && !CLD)
+            {
+                if (g != nullptr && active)                             // asymmetry of a cloudless launch: zeros (stores only)
+                    for (int gi=0; gi<ng; ++gi) slab_store(g, c0 + gi, F(0.));
+            }
         }
         // ---- contributors beyond the NCW the boxes have room for (a band of the full gas set can have seven or more): one at a time,
         // its nodes staged into the first contributor box, its term added to the optical depths this chunk has just stored (and, in the

@@ -345,6 +345,9 @@ lw_noscat_scan_kernel(
 #ifndef RRX_LW_LACC
 #define RRX_LW_LACC 1
 #endif
+#ifndef RRX_LW_EXP_TABLE
+#define RRX_LW_EXP_TABLE 1
+#endif
 #ifndef RRX_LW_TIMING
 #define RRX_LW_TIMING 0   // diagnostic build (tools/sw_timing.sh): every wavefront adds the clocks it spends per phase of a g-point to g_lw_clk
 #endif
@@ -387,6 +390,9 @@ lw_noscat_bb_kernel(
     const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
     __shared__ F xch[4*V][NW][CL];
     __shared__ F lds_b[LITE ? (2*K+1)*V : 1][64*NW];     // per-thread columns: B_lay[K], B_lev[K+1] of the current band
+    constexpr bool ETAB = sizeof(F) == 8 && RRX_LW_EXP_TABLE;
+    __shared__ F lds_etab[ETAB ? 64 : 1];
+    if constexpr (ETAB) { exp_table_fill(lds_etab); __syncthreads(); }
     int icol = wave_col0 + cl*V;
     const bool active = icol < ncol;
     if (!active) icol = (wave_col0 < ncol) ? wave_col0 : 0;
@@ -522,7 +528,8 @@ lw_noscat_bb_kernel(
             F lsj = cur.a1[j].v[v];
             if constexpr (LITE) lsj *= lds_b[j*V+v][tid];
             const F tau_loc = (valid ? tvj : F(0.)) * cur.D.v[v];      // padding layer: tau = 0 -> trans = 1, fact = 0, sources 0 (exactly)
-            const F trans = exp_neg(-tau_loc);
+            F trans;
+            if constexpr (ETAB) trans = exp_neg(-tau_loc, lds_etab); else trans = exp_neg(-tau_loc);
             const F fact = tau_loc > tau_thres ? (F(1.) - trans) * fast_rcp(tau_loc) - trans
                                                : tau_loc * (F(.5) + tau_loc * (F(-1./3.) + tau_loc * F(1./8.)));
             const F omt = F(1.) - trans;
