@@ -2182,11 +2182,16 @@ gas_window_kernel(
         {
             stream_store_sbase<F>(sbase + size_t(u)*slab_b, idx_b, v);
         };
-        auto gstep = [&](auto U_, auto SAME_, auto ACT_, const int gi0)
+        // (v) FULL_: every contributor of the chunk spans the whole chunk (the rule: intervals are band-aligned) -- the list is walked
+        // until it ends (one compare per contributor present, none for the places behind the last one); otherwise the masks.
+        // (Straight-line copies per contributor count, no tests at all, cost registers whatever the read-ahead: fp32 91 -> 127-167
+        //  VGPRs, fp64 47-180 spilled.)
+        auto gstep = [&](auto U_, auto SAME_, auto ACT_, auto FULL_, const int gi0)
         {
             constexpr int U = decltype(U_)::value;
             constexpr bool SAME = decltype(SAME_)::value;
             constexpr bool ACT = decltype(ACT_)::value;
+            constexpr bool FULL = decltype(FULL_)::value;
             Vec2 a0[U], a1[U], a2[U], a3[U]; F k4[U], k5[U], k6[U], k7[U], t[U];
             #pragma unroll
             for (int u=0; u<U; ++u)
@@ -2212,7 +2217,8 @@ gas_window_kernel(
             #pragma unroll
             for (int i=0; i<NCW; ++i)                                   // ascending contributor index: the reference's order
             {
-                if ((cmask[i] >> gi0) & 1u)
+                if constexpr (FULL) { if (i >= n) break; }
+                if (FULL || ((cmask[i] >> gi0) & 1u))
                 {
                     Vec2 c0v[U], c1v[U]; F m2[U], m3[U];
                     #pragma unroll
@@ -2314,6 +2320,12 @@ gas_window_kernel(
         bool chunk_full = true;
         #pragma unroll
         for (int i=0; i<NCW; ++i) if (i < n && !(slo[i] <= c0 && shi[i] >= gend)) chunk_full = false;
+#ifndef RRX_GW_COUNTED
+#define RRX_GW_COUNTED 1
+#endif
+#ifndef RRX_GW_PAIR32_SW
+#define RRX_GW_PAIR32_SW 0
+#endif
 #ifndef RRX_GW_PAIR32
 #define RRX_GW_PAIR32 1    // fp32 pairs the g-points of the fractions form only (LW stage 1.78 -> 1.69 ms at C4; SW 1.38 -> 1.49 paired)
 #endif
@@ -2329,24 +2341,29 @@ gas_window_kernel(
         //  at C4; with the bit masks the fractions form gains from pairs, RRX_GW_PAIR32 above, the SW forms still do not)
         // (fractions form, fp64: paired it spills 72 B per lane and is still 3 % faster now that nothing in its loop waits on `vmcnt` --
         //  2.76 -> 2.68 ms, two boxes; before the band look-up left the loop it was 3 % slower. Not in the all-sky form.)
-        constexpr int PAIR = (RRX_GW_PAIR && (sizeof(F) == 8 || (RRX_GW_PAIR32 && PF)) && ((RRX_GW_PAIR_PF && !CLD) || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
-        auto gloop = [&](auto SAME_, auto ACT_)
+        constexpr int PAIR = (RRX_GW_PAIR && (sizeof(F) == 8 || (RRX_GW_PAIR32 && (PF || RRX_GW_PAIR32_SW))) && ((RRX_GW_PAIR_PF && !CLD) || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
+        auto gloop = [&](auto SAME_, auto ACT_, auto FULL_)
         {
             for (int gi=0; gi<ng; )
             {
-                if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, SAME_, ACT_, gi); gi += 2; }
-                else { gstep(std::integral_constant<int,1>{}, SAME_, ACT_, gi); gi += 1; }
+                if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, SAME_, ACT_, FULL_, gi); gi += 2; }
+                else { gstep(std::integral_constant<int,1>{}, SAME_, ACT_, FULL_, gi); gi += 1; }
             }
         };
         if (RRX_GW_ABL != 3)
         {
-            if (wave_all_active)
+            using T_ = std::true_type; using F_ = std::false_type;
+            if (RRX_GW_COUNTED && wave_all_active && chunk_full)
             {
-                if (wave_same_eta) gloop(std::true_type{}, std::true_type{}); else gloop(std::false_type{}, std::true_type{});
+                if (wave_same_eta) gloop(T_{}, T_{}, T_{}); else gloop(F_{}, T_{}, T_{});
+            }
+            else if (wave_all_active)
+            {
+                if (wave_same_eta) gloop(T_{}, T_{}, F_{}); else gloop(F_{}, T_{}, F_{});
             }
             else
             {
-                if (wave_same_eta) gloop(std::true_type{}, std::false_type{}); else gloop(std::false_type{}, std::false_type{});
+                if (wave_same_eta) gloop(T_{}, F_{}, F_{}); else gloop(F_{}, F_{}, F_{});
             }
             if constexpr (MODE != 2 && !CLD)
             {
