@@ -17,7 +17,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 find $OUT/kt_$NAME -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_rocprofv3_kernel_stats_$NAME.csv \;
 find $OUT/kt_$NAME -name "*kernel_trace.csv" -delete
 for c in FETCH_SIZE WRITE_SIZE SQ; do
-  [ $c = SQ ] && CTRS="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" || CTRS=$c
+  [ $c = SQ ] && CTRS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" || CTRS=$c
   timeout -k 10 400 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_${NAME}_$c -o pmc -- python3 $REPO/bench.py "$@" --cpu-cols 0 --steps 3 --warmup 1 > $OUT/pmc_${NAME}_$c.log 2>&1 || echo "pmc $NAME $c FAILED"
 done
 cd $REPO

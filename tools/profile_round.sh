@@ -22,7 +22,7 @@ for mode in broadband per-gpoint; do
   find $OUT/kt_$mode -name "*kernel_trace.csv" -delete
   echo "kernel trace $mode done"
   for c in FETCH_SIZE WRITE_SIZE SQ; do
-    [ $c = SQ ] && CTRS="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" || CTRS=$c
+    [ $c = SQ ] && CTRS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" || CTRS=$c
     timeout -k 10 400 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_${mode}_$c -o pmc -- python3 $REPO/bench.py --flux-mode $mode --cpu-cols 0 --steps 3 --warmup 1 > $OUT/pmc_${mode}_$c.log 2>&1 || echo "pmc $mode $c FAILED"
     echo "pmc $mode $c done"
   done
