@@ -7,7 +7,7 @@
 #include <vector>
 #include <algorithm>
 constexpr int ITERS = 2048;
-enum Op { ADDU32, MOV32, LSHLADD, ADDF32, FMA32, SALU8, VALU8_SALU8, VALU8_SALU16, VALU8_BR4, DSREAD_DEP, DSREAD_IND4 };
+enum Op { ADDU32, MOV32, LSHLADD, ADDF32, FMA32, SALU8, VALU8_SALU8, VALU8_SALU16, VALU8_BR4, DSREAD_DEP, DSREAD_IND4, VALU8_NOP8, VALU8_WAIT8, FMA64_SALU8, FMA64 };
 
 template<int OP>
 __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* ticks, const float seed, const int one)
@@ -18,6 +18,8 @@ __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* tic
     float f0 = seed + lane, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3, f4 = f0 + 4, f5 = f0 + 5, f6 = f0 + 6, f7 = f0 + 7;
     int i0 = lane, i1 = lane + 1, i2 = lane + 2, i3 = lane + 3, i4 = lane + 4, i5 = lane + 5, i6 = lane + 6, i7 = lane + 7;
     int s0 = one, s1 = one + 1, s2 = one + 2, s3 = one + 3;
+    const double dseed = seed;
+    double d0 = dseed + lane, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     #pragma unroll 1
@@ -45,6 +47,19 @@ __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* tic
             asm volatile("v_fmac_f32 %0, %12, %12\ns_add_u32 %8, %8, %9\ns_add_u32 %9, %9, %10\nv_fmac_f32 %1, %12, %12\ns_add_u32 %10, %10, %11\ns_add_u32 %11, %11, %8\nv_fmac_f32 %2, %12, %12\ns_add_u32 %8, %8, %9\ns_add_u32 %9, %9, %10\nv_fmac_f32 %3, %12, %12\ns_add_u32 %10, %10, %11\ns_add_u32 %11, %11, %8\n"
                          "v_fmac_f32 %4, %12, %12\ns_add_u32 %8, %8, %9\ns_add_u32 %9, %9, %10\nv_fmac_f32 %5, %12, %12\ns_add_u32 %10, %10, %11\ns_add_u32 %11, %11, %8\nv_fmac_f32 %6, %12, %12\ns_add_u32 %8, %8, %9\ns_add_u32 %9, %9, %10\nv_fmac_f32 %7, %12, %12\ns_add_u32 %10, %10, %11\ns_add_u32 %11, %11, %8"
                          : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(seed) : "scc");
+        if constexpr (OP == VALU8_NOP8)        // s_nop 0 after every vector instruction
+            asm volatile("v_fmac_f32 %0, %8, %8\ns_nop 0\nv_fmac_f32 %1, %8, %8\ns_nop 0\nv_fmac_f32 %2, %8, %8\ns_nop 0\nv_fmac_f32 %3, %8, %8\ns_nop 0\nv_fmac_f32 %4, %8, %8\ns_nop 0\nv_fmac_f32 %5, %8, %8\ns_nop 0\nv_fmac_f32 %6, %8, %8\ns_nop 0\nv_fmac_f32 %7, %8, %8\ns_nop 0"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(seed));
+        if constexpr (OP == VALU8_WAIT8)       // s_waitcnt with nothing outstanding after every vector instruction
+            asm volatile("v_fmac_f32 %0, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %1, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %2, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %3, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %4, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %5, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %6, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)\nv_fmac_f32 %7, %8, %8\ns_waitcnt vmcnt(0) lgkmcnt(0)"
+                         : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(seed));
+        if constexpr (OP == FMA64)
+            asm volatile("v_fmac_f64 %0, %8, %8\nv_fmac_f64 %1, %8, %8\nv_fmac_f64 %2, %8, %8\nv_fmac_f64 %3, %8, %8\nv_fmac_f64 %4, %8, %8\nv_fmac_f64 %5, %8, %8\nv_fmac_f64 %6, %8, %8\nv_fmac_f64 %7, %8, %8"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(dseed));
+        if constexpr (OP == FMA64_SALU8)       // the solvers' case: fp64 vector instructions with a scalar one after each
+            asm volatile("v_fmac_f64 %0, %12, %12\ns_add_u32 %8, %8, %9\nv_fmac_f64 %1, %12, %12\ns_add_u32 %9, %9, %10\nv_fmac_f64 %2, %12, %12\ns_add_u32 %10, %10, %11\nv_fmac_f64 %3, %12, %12\ns_add_u32 %11, %11, %8\n"
+                         "v_fmac_f64 %4, %12, %12\ns_add_u32 %8, %8, %9\nv_fmac_f64 %5, %12, %12\ns_add_u32 %9, %9, %10\nv_fmac_f64 %6, %12, %12\ns_add_u32 %10, %10, %11\nv_fmac_f64 %7, %12, %12\ns_add_u32 %11, %11, %8"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(dseed) : "scc");
         if constexpr (OP == VALU8_BR4)         // eight vector instructions with four not-taken and taken scalar branches between them
             asm volatile("v_fmac_f32 %0, %9, %9\nv_fmac_f32 %1, %9, %9\ns_cmp_lg_u32 %8, 0\ns_cbranch_scc1 1f\nv_fmac_f32 %2, %9, %9\n1:\nv_fmac_f32 %2, %9, %9\nv_fmac_f32 %3, %9, %9\ns_cmp_eq_u32 %8, 0\ns_cbranch_scc1 2f\n2:\nv_fmac_f32 %4, %9, %9\nv_fmac_f32 %5, %9, %9\ns_cmp_lg_u32 %8, 0\ns_cbranch_scc1 3f\nv_fmac_f32 %6, %9, %9\n3:\nv_fmac_f32 %6, %9, %9\ns_cmp_eq_u32 %8, 0\ns_cbranch_scc1 4f\n4:\nv_fmac_f32 %7, %9, %9"
                          : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "s"(one), "v"(seed) : "scc");
@@ -61,7 +76,7 @@ __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* tic
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x*blockDim.x + threadIdx.x] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7 + s0 + s1 + s2 + s3;
+    out[blockIdx.x*blockDim.x + threadIdx.x] = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7 + s0 + s1 + s2 + s3 + float(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
     if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
@@ -95,6 +110,10 @@ int main()
     run<VALU8_SALU8>("v_fmac + s_add alternating (per v)", 8, out, ticks);
     run<VALU8_SALU16>("v_fmac + 2 s_add (per v)", 8, out, ticks);
     run<VALU8_BR4>("10 v_fmac + 4 cmp/branch (per v)", 10, out, ticks);
+    run<VALU8_NOP8>("v_fmac + s_nop 0 (per v)", 8, out, ticks);
+    run<VALU8_WAIT8>("v_fmac + s_waitcnt (per v)", 8, out, ticks);
+    run<FMA64>("v_fmac_f64", 8, out, ticks);
+    run<FMA64_SALU8>("v_fmac_f64 + s_add alternating (per v)", 8, out, ticks);
     run<DSREAD_DEP>("ds_read dependent (per read)", 8, out, ticks);
     run<DSREAD_IND4>("ds_read 8 together (per read)", 8, out, ticks);
     return 0;
