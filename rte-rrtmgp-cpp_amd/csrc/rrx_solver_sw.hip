@@ -39,6 +39,12 @@ constexpr int BB_EVALS = RRX_SW_BB_EVALS;   // fused broadband form: two_stream 
 #ifndef RRX_SW_MINWAVES2
 #define RRX_SW_MINWAVES2 2
 #endif
+#ifndef RRX_SW_F32_NW
+#define RRX_SW_F32_NW 4        // wavefronts per workgroup of the fp32 geometry: 4 = ONE column group (below), 8 = two (A/B)
+#endif
+#ifndef RRX_SW_F32_WAVES1
+#define RRX_SW_F32_WAVES1 3    // ... and the waves per SIMD the one-group form is compiled for
+#endif
 #ifndef RRX_SW_F32_WAVES
 #define RRX_SW_F32_WAVES 2    // waves per SIMD the fp32 geometry (16 x 4 lanes, one column per lane) is compiled for
 #endif
@@ -134,8 +140,13 @@ __device__ __forceinline__ TwoStream<F> two_stream(const F tau, const F ssa, con
 // packable instructions; compiled for four waves per SIMD (128 VGPRs) this geometry spills 36-65 registers and is slower (4.44 /
 // 12.8 ms); K = 6 with six waves per column group (three waves per SIMD, no spills) 3.43 / 7.95 ms and K = 5 with eight (four
 // per SIMD) 3.61 / 8.6 ms: the wider exchanges cost what the occupancy brings.
+// Late round 4: ONE column group per workgroup (NW = W = 4, 256 threads, half the LDS) compiled for THREE waves per SIMD (<= 168
+// VGPRs: 150-168 without scratch) -- three workgroups per CU instead of one, and an fp32 instruction issues every 2.5 cycles at
+// three waves per SIMD against 3.8 at two (tools/issue_mix_bench.hip): 3.11 -> 2.24 ms at C4, 7.07 -> 5.53 ms all-sky at 32 768
+// columns. The 64-B rows of a group are then half a 128-B line whose other half belongs to the next workgroup (L2 serves it);
+// compiled for four waves per SIMD the same form spills (2.65 / 9.3 ms).
 template<typename F, int V, int K, int W, bool BB = false, bool GZ = false, bool PRE = false, bool GS = false, int NW = (W > 2 ? 2*W : 4), int CLT = 8>
-__global__ void __launch_bounds__(64*NW, (CLT == 16) ? RRX_SW_F32_WAVES : ((NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)))
+__global__ void __launch_bounds__(64*NW, (CLT == 16) ? ((NW == 4) ? RRX_SW_F32_WAVES1 : RRX_SW_F32_WAVES) : ((NW > 4) ? 1 : ((W == 2 && V*sizeof(F) <= 8) ? RRX_SW_MINWAVES2 : RRX_SW_MINWAVES)))
 sw_2stream_scan_kernel(
         const int ncol, const int nlay, const int ngpt, const int top_at_1,
         const F* __restrict__ tau, const F* __restrict__ ssa, const F* __restrict__ g, const F* __restrict__ mu0,
@@ -801,7 +812,7 @@ bool launch_scan_bb(hipStream_t st,
     const bool pre = tuning().sw_variant != 8 && size_t(ncol)*nlay < (size_t(1) << 31)
                      && (sizeof(F) == 8 ? g == nullptr : (V == 1 && CLT == 16));
     // few column groups: the g-point loop is split over grid.y, partial sums added in range order afterwards
-    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt, (NW > 4) ? 256 : 512));      // (one or two workgroups per CU)
+    const int gper = ceil_div(ngpt, broadband_gsplit(groups, ngpt, (NW > 4) ? 256 : ((CLT == 16) ? 256*RRX_SW_F32_WAVES1 : 512)));      // (one or two workgroups per CU)
     const int nsplit = ceil_div(ngpt, gper);               // no empty range: every workgroup's first g-point exists (it is prefetched)
     const size_t nlevcol = size_t(ncol)*(nlay+1);
     StreamScratch scratch(st);
@@ -865,6 +876,12 @@ int sw_solver_2stream_impl(
         // per-lane form of rounds 1-3 for A/B runs
         if constexpr (sizeof(F) == 4)
         {
+            // up to 143 layers (nine per lane): one column group per workgroup at three waves per SIMD; 144-191 (twelve per lane, which
+            // spills at 168 VGPRs): two groups per workgroup at two waves per SIMD
+            if (g_sw_variant != 9 && ceil_div(nlay+1, 16) <= 9 &&
+                launch_scan_bb<F,1,4,16,RRX_SW_F32_NW>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
+                                                       inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
+                return 0;
             if (g_sw_variant != 9 &&
                 launch_scan_bb<F,1,4,16>(st, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir, sfc_alb_dif,
                                          inc_flux_dir, dif, flux_up_loc, flux_dn_loc, flux_dir_loc))
