@@ -2186,12 +2186,14 @@ gas_window_kernel(
         // until it ends (one compare per contributor present, none for the places behind the last one); otherwise the masks.
         // (Straight-line copies per contributor count, no tests at all, cost registers whatever the read-ahead: fp32 91 -> 127-167
         //  VGPRs, fp64 47-180 spilled.)
-        auto gstep = [&](auto U_, auto SAME_, auto ACT_, auto FULL_, const int gi0)
+        // FAST_ = (iv) and (v) together and the chunk inside one band (Planck functions, by-band cloud values): the rule. Everything
+        // else -- a wavefront of the last column block, an interval that ends inside the chunk, a band boundary inside it -- takes the
+        // one general copy of the loop.
+        auto gstep = [&](auto U_, auto SAME_, auto FAST_, const int gi0)
         {
             constexpr int U = decltype(U_)::value;
             constexpr bool SAME = decltype(SAME_)::value;
-            constexpr bool ACT = decltype(ACT_)::value;
-            constexpr bool FULL = decltype(FULL_)::value;
+            constexpr bool ACT = decltype(FAST_)::value, FULL = decltype(FAST_)::value, ONE = decltype(FAST_)::value;
             Vec2 a0[U], a1[U], a2[U], a3[U]; F k4[U], k5[U], k6[U], k7[U], t[U];
             #pragma unroll
             for (int u=0; u<U; ++u)
@@ -2258,7 +2260,7 @@ gas_window_kernel(
             for (int u=0; u<U; ++u)
             {
                 const int gi = gi0 + u, ig = c0 + gi;
-                if constexpr (CLD)
+                if constexpr (CLD && !ONE)
                 {
                     if (!cld_one_band)              // (a chunk with a band boundary inside: not the rule)
                     {
@@ -2294,10 +2296,13 @@ gas_window_kernel(
                     F v4 = p0.y, v5 = p1.y, v6 = p2.y, v7 = p3.y;
                     if constexpr (!SAME) { v4 = wp[m10].y; v5 = wp[m10 + NTW].y; v6 = wp[m10 + NEW*NTW].y; v7 = wp[m10 + NEW*NTW + NTW].y; }
                     const F pfrac = (fm[0]*p0.x + fm[1]*p1.x + fm[2]*p2.x + fm[3]*p3.x) + (fm[4]*v4 + fm[5]*v5 + fm[6]*v6 + fm[7]*v7);
-                    if (!one_band)                                  // (a chunk with a band boundary inside: not the rule)
+                    if constexpr (!ONE)
                     {
-                        const int ibnd = rfl(pa.gpoint_bands[ig]) - 1;
-                        if (ibnd != cur_bnd) band_update(ibnd);
+                        if (!one_band)                              // (a chunk with a band boundary inside: not the rule)
+                        {
+                            const int ibnd = rfl(pa.gpoint_bands[ig]) - 1;
+                            if (ibnd != cur_bnd) band_update(ibnd);
+                        }
                     }
                     if (ACT || active)
                     {
@@ -2342,28 +2347,29 @@ gas_window_kernel(
         // (fractions form, fp64: paired it spills 72 B per lane and is still 3 % faster now that nothing in its loop waits on `vmcnt` --
         //  2.76 -> 2.68 ms, two boxes; before the band look-up left the loop it was 3 % slower. Not in the all-sky form.)
         constexpr int PAIR = (RRX_GW_PAIR && (sizeof(F) == 8 || (RRX_GW_PAIR32 && (PF || RRX_GW_PAIR32_SW))) && ((RRX_GW_PAIR_PF && !CLD) || !PF) && !(RRX_GW_NOPAIR_CLD && CLD && MODE == 1)) ? 2 : 1;
-        auto gloop = [&](auto SAME_, auto ACT_, auto FULL_)
+        auto gloop = [&](auto SAME_, auto FAST_)
         {
-            for (int gi=0; gi<ng; )
+            int gi = 0;
+            if constexpr (PAIR == 2)                                    // (pairs need no range tests: only where chunk_full)
             {
-                if (PAIR == 2 && chunk_full && gi + 1 < ng) { gstep(std::integral_constant<int,PAIR>{}, SAME_, ACT_, FULL_, gi); gi += 2; }
-                else { gstep(std::integral_constant<int,1>{}, SAME_, ACT_, FULL_, gi); gi += 1; }
+                if (decltype(FAST_)::value || chunk_full)
+                    for (; gi + 1 < ng; gi += 2) gstep(std::integral_constant<int,2>{}, SAME_, FAST_, gi);
             }
+            for (; gi < ng; ++gi) gstep(std::integral_constant<int,1>{}, SAME_, FAST_, gi);
         };
         if (RRX_GW_ABL != 3)
         {
             using T_ = std::true_type; using F_ = std::false_type;
-            if (RRX_GW_COUNTED && wave_all_active && chunk_full)
+            bool fast = RRX_GW_COUNTED && wave_all_active && chunk_full;
+            if constexpr (CLD) fast = fast && cld_one_band;
+            if constexpr (PF) fast = fast && one_band;
+            if (fast)
             {
-                if (wave_same_eta) gloop(T_{}, T_{}, T_{}); else gloop(F_{}, T_{}, T_{});
-            }
-            else if (wave_all_active)
-            {
-                if (wave_same_eta) gloop(T_{}, T_{}, F_{}); else gloop(F_{}, T_{}, F_{});
+                if (wave_same_eta) gloop(T_{}, T_{}); else gloop(F_{}, T_{});
             }
             else
             {
-                if (wave_same_eta) gloop(T_{}, F_{}, F_{}); else gloop(F_{}, F_{}, F_{});
+                if (wave_same_eta) gloop(T_{}, F_{}); else gloop(F_{}, F_{});
             }
             if constexpr (MODE != 2 && !CLD)
             {
