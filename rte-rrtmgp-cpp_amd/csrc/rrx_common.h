@@ -226,6 +226,18 @@ namespace rrx
     // fp32: v_sqrt_f32 (1 ulp) without the library's scaling of denormal arguments
     __device__ __forceinline__ float sqrt_pos(const float x) { return __builtin_amdgcn_sqrtf(x); }
 
+    // Workgroup index -> work item such that items handled by ONE XCD (its own L2) are consecutive. The dispatcher deals
+    // workgroups round-robin over the eight XCDs (workgroup w runs on XCD w % 8), so neighbouring items of the natural order sit
+    // behind eight different L2s; where neighbours share cache lines (a column group of 16 fp32 columns is half a 128-B line) every
+    // line was then fetched twice from HBM (PMC: 2.0 x the algorithmic bytes). With this map XCD x handles items
+    // [x n/8, (x+1) n/8) in dispatch order, so the two halves of a line meet in one L2 within a few workgroups of each other.
+    __device__ __forceinline__ int xcd_contiguous(const int w, const int n)
+    {
+        constexpr int NXCD = 8;
+        const int per = n / NXCD, whole = per*NXCD;
+        return (w < whole) ? (w % NXCD)*per + w / NXCD : w;             // (the n % 8 last items keep their place)
+    }
+
     inline int ceil_div(const long long a, const long long b) { return int((a + b - 1) / b); }
 
     // The device's default memory pool keeps what is freed into it (its release threshold is lifted once per thread and device), so

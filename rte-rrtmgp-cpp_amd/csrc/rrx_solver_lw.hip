@@ -387,7 +387,9 @@ lw_noscat_bb_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & (CL-1), ll = lane / CL;
     const int h = wave % W, w0 = wave - h;
-    const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
+    // (a workgroup whose row segment is half a 128-B line: the other half belongs to the next workgroup -- rrx::xcd_contiguous)
+    const int bx = ((NW/W)*CL*V*sizeof(F) < 128) ? xcd_contiguous(blockIdx.x, gridDim.x) : int(blockIdx.x);
+    const int wave_col0 = (bx*(NW/W) + wave/W) * (CL*V);
     __shared__ F xch[4*V][NW][CL];
     __shared__ F lds_b[LITE ? (2*K+1)*V : 1][64*NW];     // per-thread columns: B_lay[K], B_lev[K+1] of the current band
     constexpr bool ETAB = sizeof(F) == 8 && RRX_LW_EXP_TABLE;

@@ -39,6 +39,9 @@ constexpr int BB_EVALS = RRX_SW_BB_EVALS;   // fused broadband form: two_stream 
 #ifndef RRX_SW_MINWAVES2
 #define RRX_SW_MINWAVES2 2
 #endif
+#ifndef RRX_SW_XCD_MAP
+#define RRX_SW_XCD_MAP 1
+#endif
 #ifndef RRX_SW_F32_NW
 #define RRX_SW_F32_NW 4        // wavefronts per workgroup of the fp32 geometry: 4 = ONE column group (below), 8 = two (A/B)
 #endif
@@ -170,7 +173,9 @@ sw_2stream_scan_kernel(
     const int ll = lane / CL;
     const int h = (W >= 2) ? (wave % W) : 0;          // which part of the column this wave holds (0 = TOA side)
     [[maybe_unused]] const int w0 = wave - h;         // first wave of the column group
-    const int wave_col0 = (blockIdx.x*(NW/W) + wave/W) * (CL*V);
+    // (a workgroup whose row segment is half a 128-B line: the other half belongs to the next workgroup -- rrx::xcd_contiguous)
+    const int bx = (BB && (NW/W)*CL*V*sizeof(F) < 128 && RRX_SW_XCD_MAP) ? xcd_contiguous(blockIdx.x, gridDim.x) : int(blockIdx.x);
+    const int wave_col0 = (bx*(NW/W) + wave/W) * (CL*V);
     if constexpr (W == 1) { if (wave_col0 >= ncol) return; }
 
     // W == 2: every wave stays alive until the last barrier; lanes without a column compute on a clamped one
