@@ -10,8 +10,8 @@ for a in "--ncol 16384" "--ncol 16385" "--ncol 16000" "--ncol 16001" "--ncol 409
          "--ngpt 128 --nbnd 16" "--ngpt 224 --nbnd 14" "--dtype f32 --ncol 32768" "--dtype f32 --allsky --ncol 32768"; do
   timeout -k 10 300 python3 bench.py --cpu-cols 0 --steps 10 $a 2>/dev/null | line "[$a]"
 done
-echo "# hand-back census of the 224 / 14 set (RRX_GW_STATS=1, one step):"
-RRX_GW_STATS=1 timeout -k 10 300 python3 bench.py --cpu-cols 0 --steps 1 --warmup 0 --ngpt 224 --nbnd 14 2>&1 >/dev/null | grep "handed back" | sort | uniq -c | head -6
+echo "# hand-back census of the 224 / 14 set (RRX_GW_STATS=1):"
+RRX_GW_STATS=1 timeout -k 10 300 python3 bench.py --cpu-cols 0 --steps 1 --warmup 1 --ngpt 224 --nbnd 14 2> $OUT/census.err > /dev/null; grep -h "handed back" $OUT/census.err | sort | uniq -c | head -6
 } > $OUT/r04_other_shapes.txt
 {
 for s in 0 0.05 0.35; do for so in 0 auto; do
