@@ -361,7 +361,7 @@ __device__ unsigned long long g_lw_clk[16][8];
 #define RRX_LW_LACC32 1    // fp32, two columns per lane: g-point sums in LDS columns too (round 4: the register form spilled 37-41 VGPRs)
 #endif
 #ifndef RRX_LW_EV
-#define RRX_LW_EV 2
+#define RRX_LW_EV 1         // layers of evaluations the scheduler may interleave (2: the same speed, but the fp32 two-column form then keeps 16 B of scratch per lane)
 #endif
 // NW = wavefronts per workgroup: 4, or 8 with W = 8 for columns of up to 287 layers (round 3: eight waves x four level-lanes x
 // nine layers; one workgroup per CU then, the same two waves per SIMD).
