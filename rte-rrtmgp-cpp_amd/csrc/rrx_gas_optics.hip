@@ -166,6 +166,29 @@ __device__ __forceinline__ void add_by_band_2str(F& tau1, F& ssa1, F& g1, const 
     tau1 = tau12;
 }
 
+// The same combination where the first operand is a gas (asymmetry identically zero): the term tau1 ssa1 g1 is an exact zero and is
+// not formed, and the cloud's products tau2 ssa2 and (tau2 ssa2) g2 stand alone -- loop-invariant where a chunk lies in one band.
+// Bit for bit the result of add_by_band_2str(tau1, ssa1, g1 = 0, ...).
+template<typename F, bool FAST = false>
+__device__ __forceinline__ void add_cloud_to_gas_2str(F& tau1, F& ssa1, F& g1, const F tau2, const F ssa2, const F g2)
+{
+    const F eps = Lim<F>::tiny()*F(3.);
+    const F cw = tau2 * ssa2, cwg = cw * g2;
+    const F tau12 = tau1 + tau2;
+    const F tauscat12 = (tau1 * ssa1) + cw;
+    if constexpr (FAST)
+    {
+        g1 = cwg * fast_rcp(max(tauscat12, eps));
+        ssa1 = tauscat12 * fast_rcp(max(eps, tau12));
+    }
+    else
+    {
+        g1 = cwg / max(tauscat12, eps);
+        ssa1 = tauscat12 / max(eps, tau12);
+    }
+    tau1 = tau12;
+}
+
 template<typename F>
 struct CellState { int jt, jp_raw, itropo; F ftemp, fpress; };
 
@@ -1906,14 +1929,14 @@ gas_window_kernel(
         // per-cell scalings of this chunk's contributors (registers). Their column amounts are requested NEXT TO the staging loads --
         // behind the DMA issue in that form, ahead of the staging loads in the others -- so that both share one memory round trip
         // (round 4; evaluated behind the staging they cost a round trip of their own behind the stores in flight: ~2 k clocks per chunk).
-        F sc[NCW]; int slo[NCW], shi[NCW];
+        F sc[NCW]; int slo[NCW], shi[NCW], skoff[NCW];
         auto chunk_scalings = [&]()
         {
             #pragma unroll
             for (int i=0; i<NCW; ++i)
             {
-                sc[i] = F(0.); slo[i] = 0; shi[i] = 0;
-                if (i < n) { int koff_; sc[i] = minor_scaling(rfl(items[i])); item_meta(items, i, slo[i], shi[i], koff_); }
+                sc[i] = F(0.); slo[i] = 0; shi[i] = 0; skoff[i] = 0;
+                if (i < n) { sc[i] = minor_scaling(rfl(items[i])); item_meta(items, i, slo[i], shi[i], skoff[i]); }
             }
         };
         // ---- stage the boxes: pairs (T, T+1) are adjacent words of the tables (temperature is their fastest dimension)
@@ -1966,11 +1989,10 @@ gas_window_kernel(
                     const int slot = gi_m*MBOX + e*NTW + t;
                     const unsigned roff = unsigned(it_m + ie_m*ntemp)*SZ;
                     const F* kmin_u = rfl(itr) == 0 ? kminor_lower : kminor_upper;
-                    auto minor_node = [&](const int i) -> Vec2
+                    auto minor_node = [&](const int i) -> Vec2           // (interval and row offset: read once per chunk, by chunk_scalings above)
                     {
-                        int lo, hi, koff; item_meta(items, i, lo, hi, koff);
-                        const int kg = min(max(c0 + gi_m, lo), hi-1);                   // clamped: always a valid table row
-                        return *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(kmin_u) + unsigned((kg + koff)*tn)*SZ + roff);
+                        const int kg = min(max(c0 + gi_m, slo[i]), shi[i]-1);           // clamped: always a valid table row
+                        return *reinterpret_cast<const Vec2u*>(reinterpret_cast<const char*>(kmin_u) + unsigned((kg + skoff[i])*tn)*SZ + roff);
                     };
                     Vec2 v[3]; [[maybe_unused]] Vec2 vray;
                     if constexpr (MODE == 1)
@@ -2280,7 +2302,7 @@ gas_window_kernel(
                     if constexpr (CLD)
                     {
                         F gg = F(0.);
-                        add_by_band_2str<F, RRX_GW_FAST_BYBAND != 0>(tt, ww, gg, c_tau, c_ssa, c_g);
+                        add_cloud_to_gas_2str<F, RRX_GW_FAST_BYBAND != 0>(tt, ww, gg, c_tau, c_ssa, c_g);
                         if (ACT || active) { slab_put(sb_tau, u, tt); slab_put(sb_ssa, u, ww); slab_put(sb_g, u, gg); }
                     }
                     else if (ACT || active)
